@@ -1,0 +1,877 @@
+// gam_api.hip -- host side of libgigaam_hip.so: handle, weight re-layout, workspace,
+// per-batch orchestration of the gfx950 kernels, and the extern "C" boundary declared in
+// include/gigaam_hip.h.  One call per batch; nothing here synchronises the host except
+// workspace growth.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gigaam_hip.h"
+#include "gam_attn.h"
+#include "gam_common.h"
+#include "gam_convmod.h"
+#include "gam_decode.h"
+#include "gam_frontend.h"
+#include "gam_gemm.h"
+#include "gam_norm.h"
+#include "gam_stem.h"
+
+namespace {
+
+struct HostTensor {
+  std::vector<float> data;
+  std::vector<int64_t> shape;
+  int64_t numel() const {
+    int64_t n = 1;
+    for (auto s : shape) n *= s;
+    return n;
+  }
+};
+
+struct DevBuf {
+  float* p = nullptr;
+  size_t cap = 0;  // floats
+};
+
+struct LayerW {
+  float *ln_ff1_w, *ln_ff1_b, *ff1_w1, *ff1_b1, *ff1_w2, *ff1_b2;
+  float *ln_att_w, *ln_att_b, *wqk, *bqk, *wv, *bv, *wo, *bo;
+  float *wpos, *pos_u, *pos_v;  // rel_pos only
+  float *ln_conv_w, *ln_conv_b, *pw1_w, *pw1_b, *dw_w, *dw_b, *cn_scale, *cn_shift, *pw2_w, *pw2_b;
+  float *ln_ff2_w, *ln_ff2_b, *ff2_w1, *ff2_b1, *ff2_w2, *ff2_b2;
+  float *ln_out_w, *ln_out_b;
+};
+
+struct ProfEvent {
+  hipEvent_t a, b;
+  int cls;
+};
+
+}  // namespace
+
+struct gam_handle {
+  gam_config cfg;
+  int device = 0;
+  bool finalized = false;
+  bool has_encoder = false, has_head = false;
+  std::map<std::string, HostTensor> staged;
+  std::vector<void*> owned;
+  std::string err;
+
+  // frontend
+  float *dft_basis = nullptr, *mel_fb = nullptr;
+  int nf = 0, kpad = 0;
+  // stem
+  float *c1_w = nullptr, *c1_b = nullptr, *c2_w = nullptr, *c2_b = nullptr, *lin_w = nullptr, *lin_b = nullptr;
+  int f1 = 0, f2 = 0;  // conv2d: feature bins after stage 1 / 2
+  // layers
+  std::vector<LayerW> layers;
+  float *rot_cos = nullptr, *rot_sin = nullptr;
+  // heads
+  float *ctc_w = nullptr, *ctc_b = nullptr;
+  float *jn_enc_w = nullptr, *jn_enc_b = nullptr, *jn_pred_t = nullptr, *jn_pred_b = nullptr;
+  float *jn_out_w = nullptr, *jn_out_b = nullptr, *lstm_whh_t = nullptr, *lstm_tab = nullptr;
+
+  // workspace (grow-only)
+  DevBuf wavp, spec, img, c2, xin, y1, x, y, yr, hbuf, qk, vbuf, ctx, ubuf, zbuf, tok, logits, encp;
+  int* lens = nullptr;  // 4 * maxB ints: len0, len1, len2, enc_len
+  int lens_cap = 0;
+
+  // profiler
+  bool prof_on = false;
+  std::vector<ProfEvent> prof_events;
+  size_t prof_used = 0;
+  double prof_work[GAM_PF_NCLASS] = {0};
+  int64_t prof_launches[GAM_PF_NCLASS] = {0};
+};
+
+namespace {
+
+int fail(gam_handle* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                        \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(h, -2, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+float* upload(gam_handle* h, const std::vector<float>& v) {
+  float* d = nullptr;
+  if (hipMalloc(&d, std::max<size_t>(v.size(), 4) * sizeof(float)) != hipSuccess) return nullptr;
+  if (!v.empty() && hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  h->owned.push_back(d);
+  return d;
+}
+
+int ensure(gam_handle* h, DevBuf& b, size_t floats) {
+  if (floats <= b.cap) return 0;
+  if (b.p) HIPCHK(h, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  HIPCHK(h, hipMalloc(&b.p, floats * sizeof(float)));
+  b.cap = floats;
+  return 0;
+}
+
+const HostTensor* find(gam_handle* h, const std::string& key) {
+  auto it = h->staged.find(key);
+  return it == h->staged.end() ? nullptr : &it->second;
+}
+
+// ---- profiler: one event pair per launch, on the launch stream ----
+struct ProfScope {
+  gam_handle* h;
+  hipStream_t s;
+  ProfEvent* ev = nullptr;
+  ProfScope(gam_handle* h_, hipStream_t s_, int cls, double work) : h(h_), s(s_) {
+    if (!h->prof_on) return;
+    if (h->prof_used == h->prof_events.size()) {
+      ProfEvent e;
+      if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
+      h->prof_events.push_back(e);
+    }
+    ev = &h->prof_events[h->prof_used++];
+    ev->cls = cls;
+    h->prof_work[cls] += work;
+    h->prof_launches[cls] += 1;
+    hipEventRecord(ev->a, s);
+  }
+  ~ProfScope() {
+    if (ev) hipEventRecord(ev->b, s);
+  }
+};
+
+int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a, int act, int cls = GAM_PF_GEMM) {
+  ProfScope ps(h, s, cls, 2.0 * (double)a.M * (double)a.N * (double)a.K);
+  hipError_t e = gam_launch_gemm(a, act, s);
+  if (e != hipSuccess) return fail(h, -2, "gemm launch (M=%d N=%d K=%d): %s", a.M, a.N, a.K, hipGetErrorString(e));
+  return 0;
+}
+
+GamGemmArgs gemm_args(const float* A, long lda, const float* W, const float* bias, float* C, long ldc, int M, int N, int K) {
+  GamGemmArgs g;
+  memset(&g, 0, sizeof g);
+  g.A = A; g.W = W; g.bias = bias; g.C = C; g.R = nullptr;
+  g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldc = ldc; g.ldr = ldc; g.alpha = 1.0f;
+  g.rpb = 1; g.fdiv = 1;
+  return g;
+}
+
+int layernorm(gam_handle* h, hipStream_t s, GamLnArgs a, int mode) {
+  const double bytes = (double)a.rows * a.d * 4.0 * (mode == 0 ? 2.0 : 3.0);
+  ProfScope ps(h, s, GAM_PF_NORM, bytes);
+  hipError_t e = gam_launch_layernorm(a, mode, s);
+  if (e != hipSuccess) return fail(h, -2, "layernorm launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int64_t half_up(int64_t l) { return l <= 0 ? 0 : (l + 1) / 2; }
+
+}  // namespace
+
+// ===================================================================================
+extern "C" {
+
+int gam_abi_version(void) { return GAM_ABI_VERSION; }
+
+const char* gam_last_error(const gam_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
+  if (!cfg || !out) return -1;
+  gam_handle* h = new gam_handle();
+  h->cfg = *cfg;
+  h->device = device_id;
+  *out = h;
+  const gam_config& c = h->cfg;
+  if (c.d_model <= 0 || c.n_heads <= 0 || c.d_model % c.n_heads != 0)
+    return fail(h, -1, "bad d_model/n_heads %d/%d", c.d_model, c.n_heads);
+  if (c.d_model / c.n_heads != GAM_ATT_DK) return fail(h, -1, "head dim %d unsupported (kernels are built for %d)", c.d_model / c.n_heads, GAM_ATT_DK);
+  if (c.d_model % 64 != 0 || c.d_model > 1024) return fail(h, -1, "d_model %d unsupported", c.d_model);
+  if (c.subsampling_factor != 4) return fail(h, -1, "subsampling_factor %d unsupported", c.subsampling_factor);
+  if (c.subsampling == GAM_SUBS_CONV2D && c.subs_kernel_size != 3) return fail(h, -1, "conv2d stem needs kernel 3");
+  if (c.subsampling == GAM_SUBS_CONV1D && c.subs_kernel_size != 5) return fail(h, -1, "conv1d stem needs kernel 5");
+  if (c.win_length != c.n_fft) return fail(h, -1, "win_length != n_fft unsupported");
+  if (c.n_mels > 64 || c.n_mels != c.feat_in) return fail(h, -1, "n_mels %d / feat_in %d unsupported", c.n_mels, c.feat_in);
+  if (c.head_type == GAM_HEAD_RNNT && (c.pred_rnn_layers != 1 || c.pred_hidden > GAM_RNNT_MAXH || c.joint_hidden > GAM_RNNT_MAXH || c.num_classes > GAM_RNNT_MAXV))
+    return fail(h, -1, "RNN-T head shape unsupported");
+  if (hipSetDevice(device_id) != hipSuccess) return fail(h, -2, "hipSetDevice(%d) failed", device_id);
+  return 0;
+}
+
+void gam_destroy(gam_handle* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  for (void* p : h->owned) hipFree(p);
+  DevBuf* bufs[] = {&h->wavp, &h->spec, &h->img, &h->c2, &h->xin, &h->y1, &h->x, &h->y, &h->yr, &h->hbuf,
+                    &h->qk, &h->vbuf, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp};
+  for (DevBuf* b : bufs)
+    if (b->p) hipFree(b->p);
+  if (h->lens) hipFree(h->lens);
+  for (auto& e : h->prof_events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  delete h;
+}
+
+static float half_to_float(uint16_t x) {
+  const uint32_t sign = (x >> 15) & 1, exp = (x >> 10) & 0x1f, man = x & 0x3ff;
+  uint32_t f;
+  if (exp == 0) {
+    if (man == 0) f = sign << 31;
+    else {
+      int e = -1; uint32_t m = man;
+      do { ++e; m <<= 1; } while (!(m & 0x400));
+      f = (sign << 31) | ((uint32_t)(127 - 15 - e) << 23) | ((m & 0x3ff) << 13);
+    }
+  } else if (exp == 31) f = (sign << 31) | 0x7f800000u | (man << 13);
+  else f = (sign << 31) | ((exp + 127 - 15) << 23) | (man << 13);
+  float r; memcpy(&r, &f, 4); return r;
+}
+
+int gam_set_weight(gam_handle* h, const char* key, const void* host_ptr, int dtype, const int64_t* shape, int ndim) {
+  if (!h || !key || !host_ptr) return -1;
+  if (h->finalized) return fail(h, -1, "gam_set_weight after gam_finalize");
+  HostTensor t;
+  for (int i = 0; i < ndim; ++i) t.shape.push_back(shape[i]);
+  const int64_t n = t.numel();
+  t.data.resize((size_t)n);
+  switch (dtype) {
+    case GAM_DTYPE_F32: memcpy(t.data.data(), host_ptr, (size_t)n * 4); break;
+    case GAM_DTYPE_F16: for (int64_t i = 0; i < n; ++i) t.data[i] = half_to_float(((const uint16_t*)host_ptr)[i]); break;
+    case GAM_DTYPE_BF16: for (int64_t i = 0; i < n; ++i) { uint32_t u = (uint32_t)((const uint16_t*)host_ptr)[i] << 16; memcpy(&t.data[i], &u, 4); } break;
+    case GAM_DTYPE_F64: for (int64_t i = 0; i < n; ++i) t.data[i] = (float)((const double*)host_ptr)[i]; break;
+    case GAM_DTYPE_I64: for (int64_t i = 0; i < n; ++i) t.data[i] = (float)((const int64_t*)host_ptr)[i]; break;
+    default: return fail(h, -1, "unknown dtype %d for %s", dtype, key);
+  }
+  h->staged[key] = std::move(t);
+  return 0;
+}
+
+#define NEED(var, key, n)                                                                          \
+  const HostTensor* var = find(h, key);                                                            \
+  if (!var) return fail(h, -3, "missing weight %s", std::string(key).c_str());                     \
+  if (var->numel() != (int64_t)(n)) return fail(h, -3, "weight %s has %lld elements, expected %lld", std::string(key).c_str(), (long long)var->numel(), (long long)(n));
+
+#define UP(dst, vec)                                   \
+  dst = upload(h, vec);                                \
+  if (!dst) return fail(h, -2, "device upload failed (%s)", #dst);
+
+int gam_finalize(gam_handle* h) {
+  if (!h) return -1;
+  if (h->finalized) return 0;
+  HIPCHK(h, hipSetDevice(h->device));
+  const gam_config& c = h->cfg;
+  const int D = c.d_model, C = c.d_model, F = c.feat_in, H = c.n_heads, dk = D / H;
+
+  // ---------------- frontend: window-folded DFT basis + mel filterbank ----------------
+  {
+    const int n = c.n_fft, nf = n / 2 + 1;
+    h->nf = nf;
+    h->kpad = (n + 31) / 32 * 32;
+    std::vector<double> win(n);
+    if (const HostTensor* w = find(h, "preprocessor.featurizer.0.spectrogram.window")) {
+      if (w->numel() != n) return fail(h, -3, "window has %lld taps, expected %d", (long long)w->numel(), n);
+      for (int i = 0; i < n; ++i) win[i] = w->data[i];
+    } else {
+      for (int i = 0; i < n; ++i) win[i] = (double)(float)(0.5 - 0.5 * cos(2.0 * M_PI * i / n));  // periodic hann
+    }
+    std::vector<float> basis((size_t)2 * nf * h->kpad, 0.f);
+    for (int k = 0; k < nf; ++k)
+      for (int i = 0; i < n; ++i) {
+        const long ki = ((long)k * i) % n;  // exact angle reduction
+        const double ang = 2.0 * M_PI * (double)ki / n;
+        basis[(size_t)k * h->kpad + i] = (float)(win[i] * cos(ang));
+        basis[(size_t)(nf + k) * h->kpad + i] = (float)(-win[i] * sin(ang));
+      }
+    UP(h->dft_basis, basis);
+    std::vector<float> fb;
+    if (const HostTensor* f = find(h, "preprocessor.featurizer.0.mel_scale.fb")) {
+      if (f->numel() != (int64_t)nf * c.n_mels) return fail(h, -3, "mel fb has %lld elements, expected %d", (long long)f->numel(), nf * c.n_mels);
+      fb = f->data;
+    } else {
+      // torchaudio melscale_fbanks(htk, norm=None, f_min 0, f_max sr/2)
+      fb.assign((size_t)nf * c.n_mels, 0.f);
+      const double fmax = c.sample_rate / 2.0, mmax = 2595.0 * log10(1.0 + fmax / 700.0);
+      std::vector<double> fpts(c.n_mels + 2);
+      for (int i = 0; i < c.n_mels + 2; ++i) fpts[i] = 700.0 * (pow(10.0, (mmax * i / (c.n_mels + 1)) / 2595.0) - 1.0);
+      for (int f = 0; f < nf; ++f) {
+        const double fr = (double)(c.sample_rate / 2) * f / (nf - 1);
+        for (int m = 0; m < c.n_mels; ++m) {
+          const double down = (fr - fpts[m]) / (fpts[m + 1] - fpts[m]), up = (fpts[m + 2] - fr) / (fpts[m + 2] - fpts[m + 1]);
+          fb[(size_t)f * c.n_mels + m] = (float)std::max(0.0, std::min(down, up));
+        }
+      }
+    }
+    UP(h->mel_fb, fb);
+  }
+
+  // ---------------- stem ----------------
+  // A handle may carry only a subset of the operators (e.g. a stand-alone
+  // FeatureExtractor or ConformerEncoder module on the Python side).
+  const std::string pe = "encoder.pre_encode.";
+  const bool build_encoder = find(h, pe + "conv.0.weight") != nullptr;
+  if (!build_encoder) {
+    // nothing to do
+  } else if (c.subsampling == GAM_SUBS_CONV2D) {
+    h->f1 = (F + 1) / 2;
+    h->f2 = (h->f1 + 1) / 2;
+    NEED(w0, pe + "conv.0.weight", (int64_t)C * 9);
+    NEED(b0, pe + "conv.0.bias", C);
+    NEED(w2, pe + "conv.2.weight", (int64_t)C * C * 9);
+    NEED(b2, pe + "conv.2.bias", C);
+    NEED(wl, pe + "out.weight", (int64_t)D * C * h->f2);
+    NEED(bl, pe + "out.bias", D);
+    UP(h->c1_w, w0->data);
+    UP(h->c1_b, b0->data);
+    // [n][c][kh][kw] -> [n][kh*3+kw][c]
+    std::vector<float> r((size_t)C * 9 * C);
+    for (int n = 0; n < C; ++n)
+      for (int ci = 0; ci < C; ++ci)
+        for (int t = 0; t < 9; ++t) r[((size_t)n * 9 + t) * C + ci] = w2->data[((size_t)n * C + ci) * 9 + t];
+    UP(h->c2_w, r);
+    UP(h->c2_b, b2->data);
+    // columns c*f2+f -> f*C+c (encoder.py:126-127 flattens channel-major)
+    std::vector<float> l((size_t)D * C * h->f2);
+    const int f2 = h->f2;
+    for (int n = 0; n < D; ++n)
+      for (int ci = 0; ci < C; ++ci)
+        for (int f = 0; f < f2; ++f) l[(size_t)n * C * f2 + (size_t)f * C + ci] = wl->data[(size_t)n * C * f2 + (size_t)ci * f2 + f];
+    UP(h->lin_w, l);
+    UP(h->lin_b, bl->data);
+  } else {
+    const int ks = c.subs_kernel_size;
+    NEED(w0, pe + "conv.0.weight", (int64_t)C * F * ks);
+    NEED(b0, pe + "conv.0.bias", C);
+    NEED(w2, pe + "conv.2.weight", (int64_t)C * C * ks);
+    NEED(b2, pe + "conv.2.bias", C);
+    // [n][f][k] -> [n][k][f]
+    std::vector<float> r0((size_t)C * ks * F), r2((size_t)C * ks * C);
+    for (int n = 0; n < C; ++n)
+      for (int f = 0; f < F; ++f)
+        for (int k = 0; k < ks; ++k) r0[((size_t)n * ks + k) * F + f] = w0->data[((size_t)n * F + f) * ks + k];
+    for (int n = 0; n < C; ++n)
+      for (int ci = 0; ci < C; ++ci)
+        for (int k = 0; k < ks; ++k) r2[((size_t)n * ks + k) * C + ci] = w2->data[((size_t)n * C + ci) * ks + k];
+    UP(h->c1_w, r0);
+    UP(h->c1_b, b0->data);
+    UP(h->c2_w, r2);
+    UP(h->c2_b, b2->data);
+  }
+
+  // ---------------- layers ----------------
+  const int DFF = D * c.ff_expansion_factor, ks = c.conv_kernel_size;
+  h->layers.resize(build_encoder ? c.n_layers : 0);
+  for (int li = 0; li < (build_encoder ? c.n_layers : 0); ++li) {
+    LayerW& L = h->layers[li];
+    memset(&L, 0, sizeof L);
+    const std::string p = "encoder.layers." + std::to_string(li) + ".";
+#define LN_(dstw, dstb, name)                 \
+  {                                           \
+    NEED(w_, p + name + ".weight", D);        \
+    NEED(b_, p + name + ".bias", D);          \
+    UP(dstw, w_->data);                       \
+    UP(dstb, b_->data);                       \
+  }
+#define LIN_(dstw, dstb, name, nout, nin)                 \
+  {                                                       \
+    NEED(w_, p + name + ".weight", (int64_t)(nout) * (nin)); \
+    NEED(b_, p + name + ".bias", nout);                   \
+    UP(dstw, w_->data);                                   \
+    UP(dstb, b_->data);                                   \
+  }
+    LN_(L.ln_ff1_w, L.ln_ff1_b, "norm_feed_forward1");
+    LIN_(L.ff1_w1, L.ff1_b1, "feed_forward1.linear1", DFF, D);
+    LIN_(L.ff1_w2, L.ff1_b2, "feed_forward1.linear2", D, DFF);
+    LN_(L.ln_att_w, L.ln_att_b, "norm_self_att");
+    {
+      NEED(wq, p + "self_attn.linear_q.weight", (int64_t)D * D);
+      NEED(bq, p + "self_attn.linear_q.bias", D);
+      NEED(wk, p + "self_attn.linear_k.weight", (int64_t)D * D);
+      NEED(bk, p + "self_attn.linear_k.bias", D);
+      std::vector<float> w(wq->data), b(bq->data);
+      w.insert(w.end(), wk->data.begin(), wk->data.end());
+      b.insert(b.end(), bk->data.begin(), bk->data.end());
+      UP(L.wqk, w);
+      UP(L.bqk, b);
+    }
+    LIN_(L.wv, L.bv, "self_attn.linear_v", D, D);
+    LIN_(L.wo, L.bo, "self_attn.linear_out", D, D);
+    if (c.self_attention_model == GAM_ATT_REL_POS) {
+      NEED(wp, p + "self_attn.linear_pos.weight", (int64_t)D * D);
+      NEED(pu, p + "self_attn.pos_bias_u", D);
+      NEED(pv, p + "self_attn.pos_bias_v", D);
+      UP(L.wpos, wp->data);
+      UP(L.pos_u, pu->data);
+      UP(L.pos_v, pv->data);
+    }
+    LN_(L.ln_conv_w, L.ln_conv_b, "norm_conv");
+    LIN_(L.pw1_w, L.pw1_b, "conv.pointwise_conv1", 2 * D, D);
+    LIN_(L.dw_w, L.dw_b, "conv.depthwise_conv", D, ks);
+    {
+      NEED(g, p + "conv.batch_norm.weight", D);
+      NEED(be, p + "conv.batch_norm.bias", D);
+      if (c.conv_norm_type == GAM_NORM_BATCH) {
+        NEED(rm, p + "conv.batch_norm.running_mean", D);
+        NEED(rv, p + "conv.batch_norm.running_var", D);
+        std::vector<float> sc(D), sh(D);
+        for (int i = 0; i < D; ++i) {
+          const float inv = 1.0f / sqrtf(rv->data[i] + 1e-5f);
+          sc[i] = g->data[i] * inv;
+          sh[i] = be->data[i] - rm->data[i] * sc[i];
+        }
+        UP(L.cn_scale, sc);
+        UP(L.cn_shift, sh);
+      } else {
+        UP(L.cn_scale, g->data);
+        UP(L.cn_shift, be->data);
+      }
+    }
+    LIN_(L.pw2_w, L.pw2_b, "conv.pointwise_conv2", D, D);
+    LN_(L.ln_ff2_w, L.ln_ff2_b, "norm_feed_forward2");
+    LIN_(L.ff2_w1, L.ff2_b1, "feed_forward2.linear1", DFF, D);
+    LIN_(L.ff2_w2, L.ff2_b2, "feed_forward2.linear2", D, DFF);
+    LN_(L.ln_out_w, L.ln_out_b, "norm_out");
+#undef LN_
+#undef LIN_
+  }
+
+  // ---------------- rotary table (encoder.py:342-355; base = pos_emb_max_len) ----------------
+  if (!build_encoder) {
+  } else if (c.self_attention_model == GAM_ATT_ROTARY) {
+    const int half = dk / 2, n = c.pos_emb_max_len;
+    std::vector<float> cs((size_t)n * half), sn((size_t)n * half);
+    for (int i = 0; i < half; ++i) {
+      const float inv_freq = 1.0f / powf((float)n, (float)(2 * i) / (float)dk);
+      for (int t = 0; t < n; ++t) {
+        const float fr = (float)t * inv_freq;
+        cs[(size_t)t * half + i] = (float)cos((double)fr);
+        sn[(size_t)t * half + i] = (float)sin((double)fr);
+      }
+    }
+    UP(h->rot_cos, cs);
+    UP(h->rot_sin, sn);
+  } else {
+    return fail(h, -4, "rel_pos attention is not built yet");
+  }
+
+  h->has_encoder = build_encoder;
+
+  // ---------------- heads ----------------
+  const bool build_head = find(h, "head.decoder_layers.0.weight") != nullptr || find(h, "head.joint.enc.weight") != nullptr;
+  h->has_head = build_head;
+  if (!build_head) {
+  } else if (c.head_type == GAM_HEAD_CTC) {
+    NEED(w, "head.decoder_layers.0.weight", (int64_t)c.num_classes * D);
+    NEED(b, "head.decoder_layers.0.bias", c.num_classes);
+    UP(h->ctc_w, w->data);
+    UP(h->ctc_b, b->data);
+  } else if (c.head_type == GAM_HEAD_RNNT) {
+    const int V = c.num_classes, PH = c.pred_hidden, JH = c.joint_hidden;
+    NEED(emb, "head.decoder.embed.weight", (int64_t)V * PH);
+    NEED(wih, "head.decoder.lstm.weight_ih_l0", (int64_t)4 * PH * PH);
+    NEED(whh, "head.decoder.lstm.weight_hh_l0", (int64_t)4 * PH * PH);
+    NEED(bih, "head.decoder.lstm.bias_ih_l0", 4 * PH);
+    NEED(bhh, "head.decoder.lstm.bias_hh_l0", 4 * PH);
+    NEED(wp, "head.joint.pred.weight", (int64_t)JH * PH);
+    NEED(bp, "head.joint.pred.bias", JH);
+    NEED(we, "head.joint.enc.weight", (int64_t)JH * D);
+    NEED(bee, "head.joint.enc.bias", JH);
+    NEED(wo, "head.joint.joint_net.1.weight", (int64_t)V * JH);
+    NEED(bo, "head.joint.joint_net.1.bias", V);
+    std::vector<float> tab((size_t)(V + 1) * 4 * PH), whh_t((size_t)PH * 4 * PH), wp_t((size_t)PH * JH);
+    for (int v = 0; v <= V; ++v)
+      for (int r = 0; r < 4 * PH; ++r) {
+        float acc = 0.f;
+        if (v < V) {
+          const float* wr = &wih->data[(size_t)r * PH];
+          const float* e = &emb->data[(size_t)v * PH];
+          for (int k = 0; k < PH; ++k) acc = fmaf(wr[k], e[k], acc);
+        }
+        tab[(size_t)v * 4 * PH + r] = (acc + bih->data[r]) + bhh->data[r];
+      }
+    for (int r = 0; r < 4 * PH; ++r)
+      for (int k = 0; k < PH; ++k) whh_t[(size_t)k * 4 * PH + r] = whh->data[(size_t)r * PH + k];
+    for (int r = 0; r < JH; ++r)
+      for (int k = 0; k < PH; ++k) wp_t[(size_t)k * JH + r] = wp->data[(size_t)r * PH + k];
+    UP(h->lstm_tab, tab);
+    UP(h->lstm_whh_t, whh_t);
+    UP(h->jn_pred_t, wp_t);
+    UP(h->jn_pred_b, bp->data);
+    UP(h->jn_enc_w, we->data);
+    UP(h->jn_enc_b, bee->data);
+    UP(h->jn_out_w, wo->data);
+    UP(h->jn_out_b, bo->data);
+  }
+  h->staged.clear();
+  h->finalized = true;
+  return 0;
+}
+
+int64_t gam_feat_frames(const gam_handle* h, int64_t n) {
+  const gam_config& c = h->cfg;
+  if (c.center) return n / c.hop_length + 1;
+  return n < c.win_length ? 0 : (n - c.win_length) / c.hop_length + 1;
+}
+
+int64_t gam_enc_frames(const gam_handle* h, int64_t t) {
+  (void)h;
+  return half_up(half_up(t));
+}
+
+// -----------------------------------------------------------------------------------
+int gam_frontend(gam_handle* h, const float* wav, const int64_t* wav_len, int B, int64_t L, float* feat,
+                 int64_t* feat_len, void* stream) {
+  if (!h || !h->finalized) return fail(h, -1, "gam_frontend before gam_finalize");
+  if (B <= 0 || L <= 0) return fail(h, -1, "bad shape B=%d L=%lld", B, (long long)L);
+  const gam_config& c = h->cfg;
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  const int hop = c.hop_length, n = c.n_fft, half = n / 2;
+  if (c.center && L <= half) return fail(h, -1, "input of %lld samples is too short for reflect padding (%d)", (long long)L, half);
+  const int64_t Tf = gam_feat_frames(h, L);
+  if (Tf <= 0) return fail(h, -1, "input of %lld samples yields no frames", (long long)L);
+  // per-utterance row stride Tfa: row m = b*Tfa + t starts at sample m*hop of the padded buffer
+  const int64_t need = (Tf - 1) * hop + h->kpad;
+  const int64_t Tfa = (need + hop - 1) / hop;
+  const int64_t Lp = Tfa * hop;
+  const int lds = (2 * h->nf + 3) / 4 * 4;
+  if (int r = ensure(h, h->wavp, (size_t)B * Lp + h->kpad + 64)) return r;
+  if (int r = ensure(h, h->spec, (size_t)B * Tfa * lds)) return r;
+  {
+    ProfScope ps(h, s, GAM_PF_FRONTEND, (double)B * (L + Lp) * 4.0);
+    // one extra "utterance row" of zeros is the slack the last rows' K padding reads
+    dim3 grid(gam_cdiv(Lp, 256), B);
+    hipLaunchKernelGGL(gam_pad_wav_kernel, grid, dim3(256), 0, s, wav, h->wavp.p, B, (long)L, (long)Lp, half, c.center);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemsetAsync(h->wavp.p + (size_t)B * Lp, 0, (h->kpad + 64) * sizeof(float), s));
+  }
+  GamGemmArgs g = gemm_args(h->wavp.p, hop, h->dft_basis, nullptr, h->spec.p, lds, (int)(B * Tfa), 2 * h->nf, h->kpad);
+  if (int r = gemm(h, s, g, GAM_ACT_NONE, GAM_PF_FRONTEND)) return r;
+  {
+    GamPowMelArgs a;
+    a.spec = h->spec.p; a.fb = h->mel_fb; a.feat = feat; a.wav_len = (const long long*)wav_len; a.feat_len = (long long*)feat_len;
+    a.B = B; a.Tfa = (int)Tfa; a.Tf = (int)Tf; a.nf = h->nf; a.n_mels = c.n_mels; a.lds = lds;
+    a.hop = hop; a.win = c.win_length; a.center = c.center;
+    ProfScope ps(h, s, GAM_PF_FRONTEND, (double)B * Tf * (2.0 * h->nf + c.n_mels) * 4.0);
+    dim3 grid(gam_cdiv(Tf, 64), B);
+    hipLaunchKernelGGL(gam_powmel_kernel, grid, dim3(256), 64 * (h->nf + 1) * sizeof(float), s, a);
+    HIPCHK(h, hipGetLastError());
+  }
+  return 0;
+}
+
+// -----------------------------------------------------------------------------------
+static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len, int B, int64_t T, float* encoded,
+                       int32_t* enc_len, int n_layers_run, float* tokens_out, hipStream_t s) {
+  if (!h || !h->finalized) return fail(h, -1, "gam_encode before gam_finalize");
+  if (!h->has_encoder) return fail(h, -1, "this handle was finalized without encoder weights");
+  const gam_config& c = h->cfg;
+  if (B <= 0 || T <= 0) return fail(h, -1, "bad shape B=%d T=%lld", B, (long long)T);
+  HIPCHK(h, hipSetDevice(h->device));
+  const int D = c.d_model, C = D, F = c.feat_in, H = c.n_heads, dk = D / H, DFF = D * c.ff_expansion_factor;
+  const int T1 = (int)half_up(T), T2 = (int)half_up(T1), Tv = T2;
+  if (Tv > c.pos_emb_max_len) return fail(h, -1, "%d encoder frames exceed pos_emb_max_len %d", Tv, c.pos_emb_max_len);
+  if (Tv <= 0) return fail(h, -1, "no encoder frames");
+  const bool conv2d = c.subsampling == GAM_SUBS_CONV2D;
+  // Ta: per-utterance row stride of every token-major buffer (>= T' ; the extra rows are
+  // treated as padding).  conv2d: image rows per utterance = 2*Ta >= T1 + 2.
+  // conv1d: stage-1 output rows per utterance = 2*Ta >= T1 + 4.
+  int Ta = conv2d ? std::max(Tv + 1, (T1 + 3) / 2) : std::max(Tv, (T1 + 5) / 2);
+  const int N = B * Ta;
+
+  if (B > h->lens_cap) {
+    if (h->lens) HIPCHK(h, hipFree(h->lens));
+    h->lens = nullptr;
+    HIPCHK(h, hipMalloc(&h->lens, (size_t)4 * B * sizeof(int)));
+    h->lens_cap = B;
+  }
+  int *len0 = h->lens, *len1 = h->lens + h->lens_cap, *len2 = h->lens + 2 * h->lens_cap, *elen = h->lens + 3 * h->lens_cap;
+  if (int r = ensure(h, h->x, (size_t)N * D)) return r;
+  if (int r = ensure(h, h->y, (size_t)N * D)) return r;
+  if (int r = ensure(h, h->yr, (size_t)N * D)) return r;
+  if (int r = ensure(h, h->hbuf, (size_t)N * DFF)) return r;
+  if (int r = ensure(h, h->qk, (size_t)N * 2 * D)) return r;
+  if (int r = ensure(h, h->vbuf, (size_t)N * D)) return r;
+  if (int r = ensure(h, h->ctx, (size_t)N * D)) return r;
+  if (int r = ensure(h, h->ubuf, (size_t)N * 2 * D)) return r;
+  if (int r = ensure(h, h->zbuf, (size_t)N * D)) return r;
+
+  {
+    ProfScope ps(h, s, GAM_PF_MISC, 0.0);
+    hipLaunchKernelGGL(gam_lengths_kernel, dim3(gam_cdiv(B, 64)), dim3(64), 0, s, (const long long*)feat_len, B, (int)T, 2,
+                       len0, len1, len2, elen);
+    HIPCHK(h, hipGetLastError());
+  }
+
+  // ------------------------------ stem ------------------------------
+  if (conv2d) {
+    const int FP = h->f1 + 1, F2 = h->f2;
+    if (int r = ensure(h, h->img, ((size_t)B * 2 * Ta + 2) * FP * C)) return r;
+    if (int r = ensure(h, h->c2, (size_t)N * F2 * C)) return r;
+    {
+      GamConv1Args a;
+      a.feat = feat; a.img = h->img.p; a.w = h->c1_w; a.bias = h->c1_b; a.len0 = len0; a.len1 = len1;
+      a.B = B; a.T = (int)T; a.F = F; a.Ta = Ta; a.FP = FP; a.C = C; a.T1 = T1;
+      ProfScope ps(h, s, GAM_PF_STEM, (double)B * 2 * Ta * FP * C * 4.0);
+      hipLaunchKernelGGL(gam_conv2d1_kernel, dim3(2 * Ta, B), dim3(256), 0, s, a);
+      HIPCHK(h, hipGetLastError());
+      // two slack rows past the last utterance (read by its padding frame only)
+      HIPCHK(h, hipMemsetAsync(h->img.p + (size_t)B * 2 * Ta * FP * C, 0, (size_t)2 * FP * C * sizeof(float), s));
+    }
+    GamGemmArgs g = gemm_args(h->img.p, 0, h->c2_w, h->c2_b, h->c2.p, C, N * F2, C, 9 * C);
+    g.a_mode = 1; g.conv_fp = FP; g.conv_c = C; g.conv_f2 = F2;
+    g.lens = len2; g.rpb = Ta * F2; g.fdiv = F2;
+    if (int r = gemm(h, s, g, GAM_ACT_RELU, GAM_PF_CONV2)) return r;
+    GamGemmArgs l = gemm_args(h->c2.p, (long)F2 * C, h->lin_w, h->lin_b, h->x.p, D, N, D, F2 * C);
+    if (int r = gemm(h, s, l, GAM_ACT_NONE)) return r;
+  } else {
+    const int ks = c.subs_kernel_size, pad = (ks - 1) / 2;
+    // stage-1 input rows per utterance: 2*T1a >= T + 2*pad ; stage-1 output = stage-2 input rows: 2*Ta
+    const int T1a = std::max(T1, (int)((T + 2 * pad + 1) / 2));
+    if (int r = ensure(h, h->xin, ((size_t)B * 2 * T1a + 8) * F)) return r;
+    if (int r = ensure(h, h->y1, ((size_t)B * 2 * Ta + 8) * C)) return r;
+    {
+      ProfScope ps(h, s, GAM_PF_STEM, (double)B * T * F * 8.0);
+      HIPCHK(h, hipMemsetAsync(h->xin.p, 0, ((size_t)B * 2 * T1a + 8) * F * sizeof(float), s));
+      HIPCHK(h, hipMemsetAsync(h->y1.p, 0, ((size_t)B * 2 * Ta + 8) * C * sizeof(float), s));
+      dim3 grid(gam_cdiv(T, 32), gam_cdiv(F, 32), B);
+      hipLaunchKernelGGL(gam_feat_to_rows_kernel, grid, dim3(256), 0, s, feat, h->xin.p, len0, B, F, (int)T, 2 * T1a, pad);
+      HIPCHK(h, hipGetLastError());
+    }
+    GamGemmArgs g1 = gemm_args(h->xin.p, 2L * F, h->c1_w, h->c1_b, h->y1.p, C, B * T1a, C, ks * F);
+    g1.lens = len1; g1.rpb = T1a; g1.fdiv = 1;
+    g1.remap = 1; g1.out_rpb = 2 * Ta; g1.out_shift = pad; g1.rows_valid = std::min(T1a, 2 * Ta - pad);
+    if (int r = gemm(h, s, g1, GAM_ACT_RELU, GAM_PF_CONV2)) return r;
+    GamGemmArgs g2 = gemm_args(h->y1.p, 2L * C, h->c2_w, h->c2_b, h->x.p, D, N, D, ks * C);
+    g2.lens = len2; g2.rpb = Ta; g2.fdiv = 1;
+    if (int r = gemm(h, s, g2, GAM_ACT_RELU, GAM_PF_CONV2)) return r;
+  }
+
+  // ------------------------------ Conformer layers ------------------------------
+  const int nl = n_layers_run < 0 ? c.n_layers : std::min(n_layers_run, c.n_layers);
+  GamLnArgs ln;
+  memset(&ln, 0, sizeof ln);
+  ln.rows = N; ln.d = D; ln.ta = Ta; ln.dk = dk; ln.eps = 1e-5f; ln.rcos = h->rot_cos; ln.rsin = h->rot_sin;
+  if (nl > 0) {
+    GamLnArgs a = ln;
+    a.x = h->x.p; a.out1 = h->y.p; a.w1 = h->layers[0].ln_ff1_w; a.b1 = h->layers[0].ln_ff1_b;
+    if (int r = layernorm(h, s, a, 0)) return r;
+  }
+  for (int li = 0; li < nl; ++li) {
+    const LayerW& L = h->layers[li];
+    // --- FFN 1 (macaron half step) ---
+    {
+      GamGemmArgs g = gemm_args(h->y.p, D, L.ff1_w1, L.ff1_b1, h->hbuf.p, DFF, N, DFF, D);
+      if (int r = gemm(h, s, g, GAM_ACT_SILU)) return r;
+      GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff1_w2, L.ff1_b2, h->x.p, D, N, D, DFF);
+      g2.R = h->x.p; g2.ldr = D; g2.alpha = 0.5f;
+      if (int r = gemm(h, s, g2, GAM_ACT_NONE)) return r;
+    }
+    // --- self attention ---
+    {
+      GamLnArgs a = ln;
+      a.x = h->x.p; a.out1 = h->y.p; a.out2 = h->yr.p; a.w1 = L.ln_att_w; a.b1 = L.ln_att_b;
+      if (int r = layernorm(h, s, a, 1)) return r;
+      GamGemmArgs gq = gemm_args(h->yr.p, D, L.wqk, L.bqk, h->qk.p, 2 * D, N, 2 * D, D);
+      if (int r = gemm(h, s, gq, GAM_ACT_NONE)) return r;
+      GamGemmArgs gv = gemm_args(h->y.p, D, L.wv, L.bv, h->vbuf.p, D, N, D, D);
+      if (int r = gemm(h, s, gv, GAM_ACT_NONE)) return r;
+      GamAttnArgs at;
+      at.q = h->qk.p; at.k = h->qk.p + D; at.v = h->vbuf.p; at.ctx = h->ctx.p;
+      at.lens = B > 1 ? len2 : nullptr;  // encoder.py:620-624: no mask at batch 1
+      at.B = B; at.Ta = Ta; at.Tv = Tv; at.H = H; at.ldq = 2 * D; at.ldv = D; at.ldo = D;
+      at.scale = 1.0f / sqrtf((float)dk);
+      {
+        ProfScope ps(h, s, GAM_PF_ATTN, 4.0 * (double)B * H * (double)Tv * Tv * dk);
+        hipError_t e = gam_launch_attn(at, dk, s);
+        if (e != hipSuccess) return fail(h, -2, "attention launch: %s", hipGetErrorString(e));
+      }
+      GamGemmArgs go = gemm_args(h->ctx.p, D, L.wo, L.bo, h->x.p, D, N, D, D);
+      go.R = h->x.p; go.ldr = D;
+      if (int r = gemm(h, s, go, GAM_ACT_NONE)) return r;
+    }
+    // --- convolution module ---
+    {
+      GamLnArgs a = ln;
+      a.x = h->x.p; a.out1 = h->y.p; a.w1 = L.ln_conv_w; a.b1 = L.ln_conv_b;
+      if (int r = layernorm(h, s, a, 0)) return r;
+      GamGemmArgs g1 = gemm_args(h->y.p, D, L.pw1_w, L.pw1_b, h->ubuf.p, 2 * D, N, 2 * D, D);
+      if (int r = gemm(h, s, g1, GAM_ACT_NONE)) return r;
+      GamConvModArgs cm;
+      cm.u = h->ubuf.p; cm.z = h->zbuf.p; cm.dw_w = L.dw_w; cm.dw_b = L.dw_b; cm.n_scale = L.cn_scale; cm.n_shift = L.cn_shift;
+      cm.lens = len2; cm.B = B; cm.Ta = Ta; cm.Tv = Tv; cm.d = D; cm.ks = c.conv_kernel_size; cm.eps = 1e-5f;
+      {
+        ProfScope ps(h, s, GAM_PF_CONVMOD, (double)N * D * 3 * 4.0);
+        hipError_t e = gam_launch_convmod(cm, c.conv_norm_type == GAM_NORM_LAYER, s);
+        if (e != hipSuccess) return fail(h, -2, "conv-module launch (k=%d): %s", cm.ks, hipGetErrorString(e));
+      }
+      GamGemmArgs g2 = gemm_args(h->zbuf.p, D, L.pw2_w, L.pw2_b, h->x.p, D, N, D, D);
+      g2.R = h->x.p; g2.ldr = D;
+      if (int r = gemm(h, s, g2, GAM_ACT_NONE)) return r;
+    }
+    // --- FFN 2 ---
+    {
+      GamLnArgs a = ln;
+      a.x = h->x.p; a.out1 = h->y.p; a.w1 = L.ln_ff2_w; a.b1 = L.ln_ff2_b;
+      if (int r = layernorm(h, s, a, 0)) return r;
+      GamGemmArgs g = gemm_args(h->y.p, D, L.ff2_w1, L.ff2_b1, h->hbuf.p, DFF, N, DFF, D);
+      if (int r = gemm(h, s, g, GAM_ACT_SILU)) return r;
+      GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff2_w2, L.ff2_b2, h->x.p, D, N, D, DFF);
+      g2.R = h->x.p; g2.ldr = D; g2.alpha = 0.5f;
+      if (int r = gemm(h, s, g2, GAM_ACT_NONE)) return r;
+    }
+    // --- norm_out (+ next layer's norm_feed_forward1) ---
+    {
+      GamLnArgs a = ln;
+      a.x = h->x.p; a.out1 = h->x.p; a.w1 = L.ln_out_w; a.b1 = L.ln_out_b;
+      if (li + 1 < nl) {
+        a.out2 = h->y.p; a.w2 = h->layers[li + 1].ln_ff1_w; a.b2 = h->layers[li + 1].ln_ff1_b;
+        if (int r = layernorm(h, s, a, 2)) return r;
+      } else {
+        if (int r = layernorm(h, s, a, 0)) return r;
+      }
+    }
+  }
+
+  // ------------------------------ outputs ------------------------------
+  {
+    ProfScope ps(h, s, GAM_PF_MISC, (double)B * Tv * D * 8.0);
+    if (encoded) {
+      hipError_t e = gam_launch_transpose(h->x.p, encoded, B, Tv, D, (size_t)Ta * D, D, (size_t)D * Tv, Tv, s);
+      if (e != hipSuccess) return fail(h, -2, "transpose launch: %s", hipGetErrorString(e));
+    }
+    if (tokens_out)
+      HIPCHK(h, hipMemcpy2DAsync(tokens_out, (size_t)Tv * D * 4, h->x.p, (size_t)Ta * D * 4, (size_t)Tv * D * 4, B, hipMemcpyDeviceToDevice, s));
+    if (enc_len) HIPCHK(h, hipMemcpyAsync(enc_len, elen, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
+  }
+  return 0;
+}
+
+int gam_encode(gam_handle* h, const float* feat, const int64_t* feat_len, int B, int64_t T, float* encoded, int32_t* enc_len,
+               void* stream) {
+  return encode_impl(h, feat, feat_len, B, T, encoded, enc_len, -1, nullptr, (hipStream_t)stream);
+}
+
+int gam_encode_ex(gam_handle* h, const float* feat, const int64_t* feat_len, int B, int64_t T, float* encoded, int32_t* enc_len,
+                  int n_layers_run, float* tokens_out, void* stream) {
+  return encode_impl(h, feat, feat_len, B, T, encoded, enc_len, n_layers_run, tokens_out, (hipStream_t)stream);
+}
+
+// -----------------------------------------------------------------------------------
+// heads: encoded [B,D,Tp] -> token-major [B*Tp, D] once, then GEMMs
+static int to_tokens(gam_handle* h, const float* encoded, int B, int64_t Tp, hipStream_t s) {
+  const int D = h->cfg.d_model;
+  if (int r = ensure(h, h->tok, (size_t)B * Tp * D)) return r;
+  ProfScope ps(h, s, GAM_PF_DECODE, (double)B * Tp * D * 8.0);
+  hipError_t e = gam_launch_transpose(encoded, h->tok.p, B, D, (int)Tp, (size_t)D * Tp, Tp, (size_t)Tp * D, D, s);
+  if (e != hipSuccess) return fail(h, -2, "transpose launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+static int ctc_logits(gam_handle* h, const float* encoded, int B, int64_t Tp, hipStream_t s) {
+  if (!h || !h->finalized) return fail(h, -1, "CTC head before gam_finalize");
+  if (h->cfg.head_type != GAM_HEAD_CTC || !h->has_head) return fail(h, -1, "model has no CTC head");
+  if (B <= 0 || Tp <= 0) return fail(h, -1, "bad shape B=%d T'=%lld", B, (long long)Tp);
+  HIPCHK(h, hipSetDevice(h->device));
+  const int D = h->cfg.d_model, V = h->cfg.num_classes;
+  if (int r = to_tokens(h, encoded, B, Tp, s)) return r;
+  if (int r = ensure(h, h->logits, (size_t)B * Tp * V)) return r;
+  GamGemmArgs g = gemm_args(h->tok.p, D, h->ctc_w, h->ctc_b, h->logits.p, V, (int)(B * Tp), V, D);
+  return gemm(h, s, g, GAM_ACT_NONE, GAM_PF_DECODE);
+}
+
+int gam_ctc_head(gam_handle* h, const float* encoded, int B, int64_t Tp, float* log_probs, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (int r = ctc_logits(h, encoded, B, Tp, s)) return r;
+  const int V = h->cfg.num_classes, rows = (int)(B * Tp);
+  ProfScope ps(h, s, GAM_PF_DECODE, (double)rows * V * 8.0);
+  hipLaunchKernelGGL(gam_log_softmax_kernel, dim3(gam_cdiv(rows, 4)), dim3(256), 0, s, h->logits.p, log_probs, rows, V);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int gam_ctc_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len, int B, int64_t Tp, int32_t* ids,
+                   int32_t* frames, int32_t* counts, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (int r = ctc_logits(h, encoded, B, Tp, s)) return r;
+  const int V = h->cfg.num_classes;
+  const size_t sm = ((size_t)Tp + 8) * sizeof(int);
+  if (sm > 60 * 1024) return fail(h, -1, "T'=%lld too long for the CTC greedy kernel", (long long)Tp);
+  ProfScope ps(h, s, GAM_PF_DECODE, (double)B * Tp * V * 4.0);
+  hipLaunchKernelGGL(gam_ctc_greedy_kernel, dim3(B), dim3(256), sm, s, h->logits.p, enc_len, (int)Tp, V, ids, frames, counts);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len, int B, int64_t Tp, int max_symbols,
+                    int32_t* ids, int32_t* frames, int32_t* counts, float* logits_dump, int32_t* dump_count, int dump_cap,
+                    void* stream) {
+  if (!h || !h->finalized) return fail(h, -1, "RNN-T head before gam_finalize");
+  if (h->cfg.head_type != GAM_HEAD_RNNT || !h->has_head) return fail(h, -1, "model has no RNN-T head");
+  if (B <= 0 || Tp <= 0 || max_symbols <= 0) return fail(h, -1, "bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(h, hipSetDevice(h->device));
+  const gam_config& c = h->cfg;
+  const int D = c.d_model, JH = c.joint_hidden;
+  if (int r = to_tokens(h, encoded, B, Tp, s)) return r;
+  if (int r = ensure(h, h->encp, (size_t)B * Tp * JH)) return r;
+  GamGemmArgs g = gemm_args(h->tok.p, D, h->jn_enc_w, h->jn_enc_b, h->encp.p, JH, (int)(B * Tp), JH, D);
+  if (int r = gemm(h, s, g, GAM_ACT_NONE, GAM_PF_DECODE)) return r;
+  GamRnntArgs a;
+  a.encp = h->encp.p; a.enc_len = enc_len; a.gate_tab = h->lstm_tab; a.whh_t = h->lstm_whh_t; a.wpred_t = h->jn_pred_t;
+  a.bpred = h->jn_pred_b; a.wout = h->jn_out_w; a.bout = h->jn_out_b; a.ids = ids; a.frames = frames; a.counts = counts;
+  a.dump = logits_dump; a.dump_count = dump_count; a.B = B; a.Tp = (int)Tp; a.V = c.num_classes; a.H = c.pred_hidden; a.JH = JH;
+  a.max_symbols = max_symbols; a.cap = (int)Tp * max_symbols; a.dump_cap = logits_dump ? dump_cap : 0;
+  ProfScope ps(h, s, GAM_PF_DECODE, 0.0);
+  hipLaunchKernelGGL(gam_rnnt_greedy_kernel, dim3(B), dim3(256), 0, s, a);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int gam_op_gemm(gam_handle* h, const float* A, const float* W, const float* bias, float* C, int M, int N, int K, int act,
+                void* stream) {
+  if (!h) return -1;
+  HIPCHK(h, hipSetDevice(h->device));
+  GamGemmArgs g = gemm_args(A, K, W, bias, C, N, M, N, K);
+  return gemm(h, (hipStream_t)stream, g, act);
+}
+
+int gam_profile_enable(gam_handle* h, int on) {
+  if (!h) return -1;
+  h->prof_on = on != 0;
+  h->prof_used = 0;
+  for (int i = 0; i < GAM_PF_NCLASS; ++i) { h->prof_work[i] = 0; h->prof_launches[i] = 0; }
+  return 0;
+}
+
+int gam_profile_read(gam_handle* h, int cls, double* ms, int64_t* launches, double* work) {
+  if (!h || cls < 0 || cls >= GAM_PF_NCLASS) return -1;
+  double tot = 0;
+  for (size_t i = 0; i < h->prof_used; ++i) {
+    ProfEvent& e = h->prof_events[i];
+    if (e.cls != cls) continue;
+    HIPCHK(h, hipEventSynchronize(e.b));
+    float t = 0;
+    HIPCHK(h, hipEventElapsedTime(&t, e.a, e.b));
+    tot += t;
+  }
+  if (ms) *ms = tot;
+  if (launches) *launches = h->prof_launches[cls];
+  if (work) *work = h->prof_work[cls];
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+// gam_convmod.h -- the element-wise middle of the Conformer convolution module
+// (reference gigaam/encoder.py:396-409), one fused HBM-bound kernel between the two
+// pointwise-conv GEMMs:
+//     GLU over channels -> zero padded frames -> depthwise Conv1d(k, groups=d) + bias
+//     -> BatchNorm1d(eval, running stats) [v1/v2]  or  LayerNorm over channels [v3]
+//     -> SiLU
+// Algorithmic traffic: read [N, 2d] + write [N, d] fp32 (147.7 MB per layer at
+// N = 16 032, d = 768).
+#pragma once
+#include "gam_common.h"
+
+struct GamConvModArgs {
+  const float* u;      // [B*Ta, 2d]  pointwise_conv1 output (bias included)
+  float* z;            // [B*Ta, d]
+  const float* dw_w;   // [d, ks]
+  const float* dw_b;   // [d]
+  const float* n_scale;  // BN: gamma/sqrt(var+eps)   | LN: weight
+  const float* n_shift;  // BN: beta - mean*scale     | LN: bias
+  const int* lens;     // valid frames per utterance
+  int B, Ta, Tv, d, ks;
+  float eps;
+};
+
+// ---- BatchNorm variant: block = 64 channels x 64 frames ----
+template <int KS>
+__global__ __launch_bounds__(256) void gam_convmod_bn_kernel(GamConvModArgs a) {
+  constexpr int TT = 64, PAD = (KS - 1) / 2, ROWS = TT + KS - 1;
+  __shared__ float tile[ROWS * 64];
+  const int tid = threadIdx.x;
+  const int cl = tid & 63, tg = tid >> 6;
+  const int b = blockIdx.z, c = blockIdx.y * 64 + cl, t0 = blockIdx.x * TT;
+  int klen = a.lens[b];
+  klen = klen < a.Tv ? klen : a.Tv;
+  const size_t rowbase = (size_t)b * a.Ta;
+  for (int rr = tg; rr < ROWS; rr += 4) {
+    const int t = t0 - PAD + rr;
+    float val = 0.f;
+    if (t >= 0 && t < klen) {
+      const float* up = a.u + (rowbase + t) * (size_t)(2 * a.d);
+      val = up[c] * gam_sigmoid(up[a.d + c]);
+    }
+    tile[rr * 64 + cl] = val;
+  }
+  float w[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k) w[k] = a.dw_w[(size_t)c * KS + k];
+  const float bias = a.dw_b[c], sc = a.n_scale[c], sh = a.n_shift[c];
+  __syncthreads();
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int tl = tg * 16 + i;
+    const int t = t0 + tl;
+    if (t >= a.Ta) break;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < KS; ++k) acc = fmaf(w[k], tile[(tl + k) * 64 + cl], acc);
+    acc += bias;
+    const float y = acc * sc + sh;
+    a.z[(rowbase + t) * (size_t)a.d + c] = gam_silu(y);
+  }
+}
+
+// ---- LayerNorm variant (v3): block = 8 frames x all channels (d <= 1024) ----
+template <int KS>
+__global__ __launch_bounds__(256) void gam_convmod_ln_kernel(GamConvModArgs a) {
+  constexpr int TT = 8, PAD = (KS - 1) / 2, ROWS = TT + KS - 1, MAXC = 4;
+  extern __shared__ __attribute__((aligned(16))) float gam_smem_cm[];
+  float* tile = gam_smem_cm;                 // [ROWS][d]
+  float* red = gam_smem_cm + ROWS * a.d;     // [4 waves][TT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, t0 = blockIdx.x * TT;
+  int klen = a.lens[b];
+  klen = klen < a.Tv ? klen : a.Tv;
+  const size_t rowbase = (size_t)b * a.Ta;
+  for (int rr = 0; rr < ROWS; ++rr) {
+    const int t = t0 - PAD + rr;
+    const bool ok = t >= 0 && t < klen;
+    const float* up = a.u + (rowbase + (ok ? t : 0)) * (size_t)(2 * a.d);
+    for (int c = tid; c < a.d; c += 256) tile[rr * a.d + c] = ok ? up[c] * gam_sigmoid(up[a.d + c]) : 0.f;
+  }
+  __syncthreads();
+  float y[MAXC][TT];
+#pragma unroll
+  for (int ci = 0; ci < MAXC; ++ci) {
+    const int c = tid + ci * 256;
+    if (c < a.d) {
+      float w[KS];
+#pragma unroll
+      for (int k = 0; k < KS; ++k) w[k] = a.dw_w[(size_t)c * KS + k];
+      const float bias = a.dw_b[c];
+#pragma unroll
+      for (int i = 0; i < TT; ++i) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) acc = fmaf(w[k], tile[(i + k) * a.d + c], acc);
+        y[ci][i] = acc + bias;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < TT; ++i) y[ci][i] = 0.f;
+    }
+  }
+  // per-frame mean over channels
+  float mean[TT], rstd[TT];
+#pragma unroll
+  for (int i = 0; i < TT; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < MAXC; ++ci) s += y[ci][i];
+    s = gam_wave_sum(s);
+    if (lane == 0) red[wave * TT + i] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TT; ++i) mean[i] = (red[i] + red[TT + i] + red[2 * TT + i] + red[3 * TT + i]) / (float)a.d;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TT; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < MAXC; ++ci) {
+      const int c = tid + ci * 256;
+      if (c < a.d) { const float dlt = y[ci][i] - mean[i]; s += dlt * dlt; }
+    }
+    s = gam_wave_sum(s);
+    if (lane == 0) red[wave * TT + i] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TT; ++i)
+    rstd[i] = 1.0f / sqrtf((red[i] + red[TT + i] + red[2 * TT + i] + red[3 * TT + i]) / (float)a.d + a.eps);
+#pragma unroll
+  for (int ci = 0; ci < MAXC; ++ci) {
+    const int c = tid + ci * 256;
+    if (c < a.d) {
+      const float g = a.n_scale[c], be = a.n_shift[c];
+#pragma unroll
+      for (int i = 0; i < TT; ++i) {
+        const int t = t0 + i;
+        if (t < a.Ta) a.z[(rowbase + t) * (size_t)a.d + c] = gam_silu((y[ci][i] - mean[i]) * rstd[i] * g + be);
+      }
+    }
+  }
+}
+
+static inline hipError_t gam_launch_convmod(const GamConvModArgs& a, int layer_norm, hipStream_t s) {
+  if (!layer_norm) {
+    if (a.d % 64 != 0) return hipErrorInvalidValue;
+    dim3 grid(gam_cdiv(a.Ta, 64), a.d / 64, a.B);
+    if (a.ks == 31) hipLaunchKernelGGL(gam_convmod_bn_kernel<31>, grid, dim3(256), 0, s, a);
+    else if (a.ks == 5) hipLaunchKernelGGL(gam_convmod_bn_kernel<5>, grid, dim3(256), 0, s, a);
+    else if (a.ks == 9) hipLaunchKernelGGL(gam_convmod_bn_kernel<9>, grid, dim3(256), 0, s, a);
+    else return hipErrorInvalidValue;
+  } else {
+    if (a.d > 1024) return hipErrorInvalidValue;
+    dim3 grid(gam_cdiv(a.Ta, 8), a.B);
+    if (a.ks == 5) {
+      const size_t sm = ((8 + 4) * a.d + 32) * sizeof(float);
+      hipLaunchKernelGGL(gam_convmod_ln_kernel<5>, grid, dim3(256), sm, s, a);
+    } else if (a.ks == 31) {
+      const size_t sm = ((8 + 30) * a.d + 32) * sizeof(float);
+      static bool attr = false;
+      if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gam_convmod_ln_kernel<31>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+      }
+      hipLaunchKernelGGL(gam_convmod_ln_kernel<31>, grid, dim3(256), sm, s, a);
+    } else if (a.ks == 9) {
+      const size_t sm = ((8 + 8) * a.d + 32) * sizeof(float);
+      hipLaunchKernelGGL(gam_convmod_ln_kernel<9>, grid, dim3(256), sm, s, a);
+    } else return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}

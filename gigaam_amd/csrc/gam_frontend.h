@@ -1,0 +1,90 @@
+// gam_frontend.h -- log-mel frontend (reference gigaam/preprocess.py:43-98 wrapping
+// torchaudio.transforms.MelSpectrogram; contract restated in SURVEY.md §8c):
+//   reflect-pad n_fft/2 (center=True) -> frames of n_fft samples every hop -> periodic
+//   Hann -> rFFT -> |X|^2 -> mel = fb^T . power (HTK, norm=None) -> log(clamp(.,1e-9,1e9)).
+// The windowed DFT is one fp32 MFMA GEMM (gam_gemm.h) whose A operand is the padded
+// waveform itself read with overlapping rows (lda = hop) and whose W operand is the
+// window-folded cos/sin basis built once at finalize; only two small HBM-bound kernels
+// remain: the padding producer and the power/mel/log consumer.
+#pragma once
+#include "gam_common.h"
+
+// wav [B, L] -> wavp [B, Lp] (+slack);  center: wavp[i] = reflect(wav, i - half)
+__global__ __launch_bounds__(256) void gam_pad_wav_kernel(const float* wav, float* wavp, int B, long L, long Lp,
+                                                          int half, int center) {
+  const int b = blockIdx.y;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= Lp) return;
+  float v = 0.f;
+  if (center) {
+    long j = i - half;
+    if (j < 0) j = -j;
+    else if (j >= L) j = 2 * (L - 1) - j;
+    if (i < L + 2 * half && j >= 0 && j < L) v = wav[(size_t)b * L + j];
+  } else {
+    if (i < L) v = wav[(size_t)b * L + i];
+  }
+  wavp[(size_t)b * Lp + i] = v;
+}
+
+struct GamPowMelArgs {
+  const float* spec;   // [B*Tfa, lds]: re[0..nf) | im[nf..2nf)
+  const float* fb;     // [nf, n_mels]
+  float* feat;         // [B, n_mels, Tf]
+  const long long* wav_len;  // [B] samples (may be null -> no feat_len output)
+  long long* feat_len;       // [B]
+  int B, Tfa, Tf, nf, n_mels, lds;
+  int hop, win, center;
+};
+
+// block: 64 frames x (n_mels <= 64) ; thread = (frame, 16-mel group)
+__global__ __launch_bounds__(256) void gam_powmel_kernel(GamPowMelArgs a) {
+  extern __shared__ float gam_smem_pm[];   // [64][nf + 1]
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, t0 = blockIdx.x * 64;
+  const int pld = a.nf + 1;
+  if (blockIdx.x == 0 && tid == 0 && a.wav_len != nullptr) {
+    const long long l = a.wav_len[b];
+    long long num = a.center ? l : l - a.win;
+    // floor division (torch div rounding_mode="floor"), preprocess.py:82-92
+    long long qd = num / a.hop;
+    if ((num % a.hop != 0) && (num < 0)) qd -= 1;
+    a.feat_len[b] = qd + 1;
+  }
+  for (int idx = tid; idx < 64 * a.nf; idx += 256) {
+    const int fl = idx / a.nf, f = idx - fl * a.nf;
+    const int t = t0 + fl;
+    float p = 0.f;
+    if (t < a.Tf) {
+      const float* sp = a.spec + ((size_t)b * a.Tfa + t) * a.lds;
+      const float re = sp[f], im = sp[a.nf + f];
+      p = re * re + im * im;
+    }
+    gam_smem_pm[fl * pld + f] = p;
+  }
+  __syncthreads();
+  const int fl = tid & 63, mg = tid >> 6;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  const float* pw = gam_smem_pm + fl * pld;
+  for (int f = 0; f < a.nf; ++f) {
+    const float p = pw[f];
+    const float* fbr = a.fb + (size_t)f * a.n_mels + mg * 16;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (mg * 16 + j < a.n_mels) acc[j] = fmaf(p, fbr[j], acc[j]);
+  }
+  const int t = t0 + fl;
+  if (t < a.Tf) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int m = mg * 16 + j;
+      if (m < a.n_mels) {
+        float v = acc[j];
+        v = fminf(fmaxf(v, 1e-9f), 1e9f);
+        a.feat[((size_t)b * a.n_mels + m) * a.Tf + t] = logf(v);
+      }
+    }
+  }
+}

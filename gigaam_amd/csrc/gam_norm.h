@@ -1,0 +1,127 @@
+// gam_norm.h -- LayerNorm over d_model (reference gigaam/encoder.py:447,449,455,469,471)
+// with the two fusions the Conformer layer allows:
+//   MODE 1: y = LN(x) and yr = RoPE(y)  -- the reference rotates the layer-normed input
+//           BEFORE the q/k projections (encoder.py:244-256, utils.py:83-100), so the
+//           rotated copy feeds the fused W_q|W_k GEMM and the plain copy feeds W_v.
+//   MODE 2: x' = LN_out(x) of layer i and y = LN_ff1(x') of layer i+1 in one pass.
+// HBM-bound: one wave per row, 16-byte loads, the row lives in registers, two-pass
+// mean/variance (fp32, eps 1e-5) like the reference's native_layer_norm.
+#pragma once
+#include "gam_common.h"
+
+#define GAM_LN_MAXJ 4  // d_model <= 1024
+
+struct GamLnArgs {
+  const float* x;
+  float* out1;        // MODE 0: y ; MODE 1: y ; MODE 2: x'
+  float* out2;        // MODE 1: rope(y) ; MODE 2: y
+  const float* w1; const float* b1;
+  const float* w2; const float* b2;   // MODE 2
+  const float* rcos; const float* rsin;  // MODE 1: [Tmax, dk/2]
+  int rows, d, ta, dk;
+  float eps;
+};
+
+__device__ __forceinline__ void gam_ln_row(float4 (&v)[GAM_LN_MAXJ], int d, int lane, float eps,
+                                           const float* w, const float* b) {
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < GAM_LN_MAXJ; ++j)
+    if ((j * 64 + lane) * 4 < d) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  const float mean = gam_wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < GAM_LN_MAXJ; ++j)
+    if ((j * 64 + lane) * 4 < d) {
+      const float a0 = v[j].x - mean, a1 = v[j].y - mean, a2 = v[j].z - mean, a3 = v[j].w - mean;
+      q += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+  const float rstd = 1.0f / sqrtf(gam_wave_sum(q) / (float)d + eps);
+#pragma unroll
+  for (int j = 0; j < GAM_LN_MAXJ; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    if (c < d) {
+      const float4 ww = *reinterpret_cast<const float4*>(w + c);
+      const float4 bb = *reinterpret_cast<const float4*>(b + c);
+      v[j].x = (v[j].x - mean) * rstd * ww.x + bb.x;
+      v[j].y = (v[j].y - mean) * rstd * ww.y + bb.y;
+      v[j].z = (v[j].z - mean) * rstd * ww.z + bb.z;
+      v[j].w = (v[j].w - mean) * rstd * ww.w + bb.w;
+    }
+  }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gam_layernorm_kernel(GamLnArgs a) {
+  __shared__ float rowbuf[MODE == 1 ? 4 * GAM_LN_MAXJ * 256 : 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row_raw = blockIdx.x * 4 + wave;
+  const bool live = row_raw < a.rows;
+  const int row = live ? row_raw : a.rows - 1;
+  const float* xr = a.x + (size_t)row * a.d;
+  float4 v[GAM_LN_MAXJ];
+#pragma unroll
+  for (int j = 0; j < GAM_LN_MAXJ; ++j) {
+    const int c = (j * 64 + lane) * 4;
+    v[j] = c < a.d ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  gam_ln_row(v, a.d, lane, a.eps, a.w1, a.b1);
+  if (live) {
+#pragma unroll
+    for (int j = 0; j < GAM_LN_MAXJ; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      if (c < a.d) *reinterpret_cast<float4*>(a.out1 + (size_t)row * a.d + c) = v[j];
+    }
+  }
+  if (MODE == 2) {
+    gam_ln_row(v, a.d, lane, a.eps, a.w2, a.b2);
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < GAM_LN_MAXJ; ++j) {
+        const int c = (j * 64 + lane) * 4;
+        if (c < a.d) *reinterpret_cast<float4*>(a.out2 + (size_t)row * a.d + c) = v[j];
+      }
+    }
+  }
+  if (MODE == 1) {
+    float* rb = rowbuf + wave * (GAM_LN_MAXJ * 256);
+#pragma unroll
+    for (int j = 0; j < GAM_LN_MAXJ; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      if (c < a.d) *reinterpret_cast<float4*>(rb + c) = v[j];
+    }
+    __syncthreads();
+    const int t = row % a.ta;
+    const int half = a.dk >> 1;
+    const float* cs = a.rcos + (size_t)t * half;
+    const float* sn = a.rsin + (size_t)t * half;
+#pragma unroll
+    for (int j = 0; j < GAM_LN_MAXJ; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      if (c < a.d) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int cc = c + e;
+          const int i = cc % a.dk;
+          const float self = rb[cc];
+          float r;
+          if (i < half) r = self * cs[i] - rb[cc + half] * sn[i];        // x*cos + (-x2)*sin
+          else          r = self * cs[i - half] + rb[cc - half] * sn[i - half];
+          o[e] = r;
+        }
+        if (live) *reinterpret_cast<float4*>(a.out2 + (size_t)row * a.d + c) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+}
+
+static inline hipError_t gam_launch_layernorm(const GamLnArgs& a, int mode, hipStream_t s) {
+  if (a.rows <= 0) return hipSuccess;
+  if (a.d % 4 != 0 || a.d > GAM_LN_MAXJ * 256) return hipErrorInvalidValue;
+  const int grid = gam_cdiv(a.rows, 4);
+  if (mode == 0) hipLaunchKernelGGL(gam_layernorm_kernel<0>, dim3(grid), dim3(256), 0, s, a);
+  else if (mode == 1) hipLaunchKernelGGL(gam_layernorm_kernel<1>, dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gam_layernorm_kernel<2>, dim3(grid), dim3(256), 0, s, a);
+  return hipGetLastError();
+}

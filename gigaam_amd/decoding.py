@@ -1,0 +1,72 @@
+"""``cfg.decoding`` slot: greedy decoders (reference gigaam/decoding.py:10-207).
+
+``decode(head, encoded [B,D,T'], lengths [B]) -> [(text, ids, frames)]``.  The
+token work (argmax/collapse, the RNN-T predictor/joint loop) runs in one HIP
+launch per batch; only the final ragged ids/frames cross PCIe, once.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from .decoder import CTCHead, RNNTHead
+
+
+class Tokenizer:
+    """Char-wise vocabulary or a SentencePiece model (reference decoding.py:10-44)."""
+
+    def __init__(self, vocab: List[str], model_path: Optional[str] = None):
+        self.charwise = model_path is None
+        if self.charwise:
+            self.vocab = vocab
+        else:
+            from sentencepiece import SentencePieceProcessor
+
+            self.model = SentencePieceProcessor()
+            self.model.load(model_path)
+
+    def decode(self, tokens: List[int]) -> str:
+        if self.charwise:
+            return "".join(self.vocab[t] for t in tokens)
+        return self.model.decode(tokens)
+
+    def __len__(self) -> int:
+        return len(self.vocab) if self.charwise else len(self.model)
+
+    def id_to_str(self, token_id: int) -> str:
+        return self.vocab[token_id] if self.charwise else self.model.IdToPiece(token_id)
+
+
+def _ragged(ids: Tensor, frames: Tensor, counts: Tensor) -> List[Tuple[List[int], List[int]]]:
+    n = counts.cpu().tolist()
+    width = max(n) if n else 0
+    ids_h = ids[:, :width].cpu()
+    fr_h = frames[:, :width].cpu()
+    return [(ids_h[i, :c].tolist(), fr_h[i, :c].tolist()) for i, c in enumerate(n)]
+
+
+class CTCGreedyDecoding:
+    def __init__(self, vocabulary: List[str], model_path: Optional[str] = None):
+        self.tokenizer = Tokenizer(vocabulary, model_path)
+        self.blank_id = len(self.tokenizer)
+
+    @torch.inference_mode()
+    def decode(self, head: CTCHead, encoded: Tensor, lengths: Tensor) -> List[Tuple[str, List[int], List[int]]]:
+        c = head.num_classes
+        assert c == len(self.tokenizer) + 1, f"Num classes {c} != len(vocab)+1 {len(self.tokenizer)+1}"
+        ids, frames, counts = head.engine.ctc_greedy(encoded, lengths)
+        return [(self.tokenizer.decode(i), i, f) for i, f in _ragged(ids, frames, counts)]
+
+
+class RNNTGreedyDecoding:
+    def __init__(self, vocabulary: List[str], model_path: Optional[str] = None, max_symbols_per_step: int = 10):
+        self.tokenizer = Tokenizer(vocabulary, model_path)
+        self.blank_id = len(self.tokenizer)
+        self.max_symbols = max_symbols_per_step
+
+    @torch.inference_mode()
+    def decode(self, head: RNNTHead, encoded: Tensor, enc_len: Tensor) -> List[Tuple[str, List[int], List[int]]]:
+        ids, frames, counts = head.engine.rnnt_greedy(encoded, enc_len, self.max_symbols)
+        return [(self.tokenizer.decode(i), i, f) for i, f in _ragged(ids, frames, counts)]

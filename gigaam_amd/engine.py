@@ -1,0 +1,233 @@
+"""HipEngine: one ``gam_handle`` (include/gigaam_hip.h) behind torch tensors.
+
+torch is plumbing here -- device memory, the current HIP stream and (in bench.py)
+torch.distributed.  All compute happens in libgigaam_hip.so; there is no eager /
+CPU fallback, and every method raises if the library or the GPU call fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any, Dict, Mapping, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import GamConfig, GigaAMHipError
+
+
+def _get(cfg: Any, key: str, default: Any = None) -> Any:
+    if cfg is None:
+        return default
+    if isinstance(cfg, Mapping):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+def build_config(pre: Any = None, enc: Any = None, head: Any = None) -> GamConfig:
+    """POD mirror of the checkpoint's cfg sub-trees.  Defaults follow the reference
+    constructors (gigaam/preprocess.py:60-65, gigaam/encoder.py:510-526)."""
+    c = GamConfig()
+    sr = _get(pre, "sample_rate", 16000)
+    c.sample_rate = sr
+    c.n_mels = _get(pre, "features", 64)
+    c.hop_length = _get(pre, "hop_length", sr // 100)
+    c.win_length = _get(pre, "win_length", sr // 40)
+    c.n_fft = _get(pre, "n_fft", sr // 40)
+    c.center = int(bool(_get(pre, "center", True)))
+    c.feat_in = _get(enc, "feat_in", 64)
+    c.n_layers = _get(enc, "n_layers", 16)
+    c.d_model = _get(enc, "d_model", 768)
+    subs = _get(enc, "subsampling", "conv2d")
+    assert subs in ("conv1d", "conv2d")  # encoder.py:48
+    c.subsampling = _lib.SUBS_CONV2D if subs == "conv2d" else _lib.SUBS_CONV1D
+    c.subs_kernel_size = _get(enc, "subs_kernel_size", 3)
+    c.subsampling_factor = _get(enc, "subsampling_factor", 4)
+    c.ff_expansion_factor = _get(enc, "ff_expansion_factor", 4)
+    att = _get(enc, "self_attention_model", "rotary")
+    assert att in ("rotary", "rel_pos"), f"Not supported attn = {att}"  # encoder.py:530-533
+    c.self_attention_model = _lib.ATT_ROTARY if att == "rotary" else _lib.ATT_REL_POS
+    c.n_heads = _get(enc, "n_heads", 16)
+    c.pos_emb_max_len = _get(enc, "pos_emb_max_len", 5000)
+    norm = _get(enc, "conv_norm_type", "batch_norm")
+    assert norm in ("batch_norm", "layer_norm")  # encoder.py:377
+    c.conv_norm_type = _lib.NORM_BATCH if norm == "batch_norm" else _lib.NORM_LAYER
+    c.conv_kernel_size = _get(enc, "conv_kernel_size", 31)
+    c.head_type = _lib.HEAD_NONE
+    if head is not None:
+        target = str(_get(head, "_target_", ""))
+        dec, jn = _get(head, "decoder"), _get(head, "joint")
+        if dec is not None and jn is not None or target.endswith("RNNTHead"):
+            c.head_type = _lib.HEAD_RNNT
+            c.num_classes = _get(dec, "num_classes")
+            c.pred_hidden = _get(dec, "pred_hidden")
+            c.pred_rnn_layers = _get(dec, "pred_rnn_layers")
+            c.joint_hidden = _get(jn, "joint_hidden")
+        else:
+            c.head_type = _lib.HEAD_CTC
+            c.num_classes = _get(head, "num_classes")
+    return c
+
+
+_DTYPES = {
+    torch.float32: _lib.DTYPE_F32, torch.float16: _lib.DTYPE_F16, torch.bfloat16: _lib.DTYPE_BF16,
+    torch.float64: _lib.DTYPE_F64, torch.int64: _lib.DTYPE_I64,
+}
+
+
+def _ptr(t: Optional[Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class HipEngine:
+    """Owns one library handle on one GPU."""
+
+    def __init__(self, config: GamConfig, state_dict: Mapping[str, Tensor], device: torch.device):
+        self.lib = _lib.load_library()
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise GigaAMHipError(f"gigaam_amd runs on a ROCm GPU only (device={device}); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise GigaAMHipError("no ROCm GPU visible to torch")
+        self.device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+        self.cfg = config
+        self._h = C.c_void_p()
+        rc = self.lib.gam_create(C.byref(config), self.device.index, C.byref(self._h))
+        self._check(rc, "gam_create")
+        for key, val in state_dict.items():
+            if not isinstance(val, Tensor):
+                continue
+            t = val.detach().to("cpu").contiguous()
+            if t.dtype not in _DTYPES:
+                t = t.to(torch.float32)
+            shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
+            rc = self.lib.gam_set_weight(self._h, key.encode(), C.c_void_p(t.data_ptr()), _DTYPES[t.dtype], shape, t.dim())
+            self._check(rc, f"gam_set_weight({key})")
+        self._check(self.lib.gam_finalize(self._h), "gam_finalize")
+
+    # ------------------------------------------------------------------ utils
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            msg = self.lib.gam_last_error(self._h)
+            raise GigaAMHipError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, t: Tensor, dtype: torch.dtype) -> Tensor:
+        return t.to(device=self.device, dtype=dtype).contiguous()
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.gam_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def feat_frames(self, n_samples: int) -> int:
+        return int(self.lib.gam_feat_frames(self._h, n_samples))
+
+    def enc_frames(self, n_feat: int) -> int:
+        return int(self.lib.gam_enc_frames(self._h, n_feat))
+
+    # ------------------------------------------------------------------ operators
+    def frontend(self, wav: Tensor, length: Tensor) -> Tuple[Tensor, Tensor]:
+        wav = self._dev(wav, torch.float32)
+        length = self._dev(length, torch.int64)
+        b, l = wav.shape
+        t = self.feat_frames(l)
+        feat = torch.empty((b, self.cfg.n_mels, t), dtype=torch.float32, device=self.device)
+        flen = torch.empty((b,), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gam_frontend(self._h, _ptr(wav), _ptr(length), b, l, _ptr(feat), _ptr(flen), self._stream())
+        self._check(rc, "gam_frontend")
+        return feat, flen
+
+    def encode(self, feat: Tensor, length: Tensor, n_layers_run: int = -1, want_tokens: bool = False):
+        feat = self._dev(feat, torch.float32)
+        length = self._dev(length, torch.int64)
+        b, f, t = feat.shape
+        if f != self.cfg.feat_in:
+            raise GigaAMHipError(f"expected [B,{self.cfg.feat_in},T] features, got {tuple(feat.shape)}")
+        tp = self.enc_frames(t)
+        enc = torch.empty((b, self.cfg.d_model, tp), dtype=torch.float32, device=self.device)
+        elen = torch.empty((b,), dtype=torch.int32, device=self.device)
+        tok = torch.empty((b, tp, self.cfg.d_model), dtype=torch.float32, device=self.device) if want_tokens else None
+        with torch.cuda.device(self.device):
+            if n_layers_run < 0 and not want_tokens:
+                rc = self.lib.gam_encode(self._h, _ptr(feat), _ptr(length), b, t, _ptr(enc), _ptr(elen), self._stream())
+            else:
+                rc = self.lib.gam_encode_ex(self._h, _ptr(feat), _ptr(length), b, t, _ptr(enc), _ptr(elen),
+                                            n_layers_run, _ptr(tok), self._stream())
+        self._check(rc, "gam_encode")
+        return (enc, elen, tok) if want_tokens else (enc, elen)
+
+    def ctc_head(self, encoded: Tensor) -> Tensor:
+        encoded = self._dev(encoded, torch.float32)
+        b, _, tp = encoded.shape
+        out = torch.empty((b, tp, self.cfg.num_classes), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gam_ctc_head(self._h, _ptr(encoded), b, tp, _ptr(out), self._stream())
+        self._check(rc, "gam_ctc_head")
+        return out
+
+    def ctc_greedy(self, encoded: Tensor, enc_len: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        encoded = self._dev(encoded, torch.float32)
+        enc_len = self._dev(enc_len, torch.int32)
+        b, _, tp = encoded.shape
+        ids = torch.empty((b, tp), dtype=torch.int32, device=self.device)
+        frames = torch.empty((b, tp), dtype=torch.int32, device=self.device)
+        counts = torch.empty((b,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gam_ctc_greedy(self._h, _ptr(encoded), _ptr(enc_len), b, tp, _ptr(ids), _ptr(frames),
+                                         _ptr(counts), self._stream())
+        self._check(rc, "gam_ctc_greedy")
+        return ids, frames, counts
+
+    def rnnt_greedy(self, encoded: Tensor, enc_len: Tensor, max_symbols: int, dump_cap: int = 0):
+        encoded = self._dev(encoded, torch.float32)
+        enc_len = self._dev(enc_len, torch.int32)
+        b, _, tp = encoded.shape
+        cap = tp * max_symbols
+        ids = torch.empty((b, cap), dtype=torch.int32, device=self.device)
+        frames = torch.empty((b, cap), dtype=torch.int32, device=self.device)
+        counts = torch.empty((b,), dtype=torch.int32, device=self.device)
+        dump = dcount = None
+        if dump_cap > 0:
+            dump = torch.zeros((b, dump_cap, self.cfg.num_classes), dtype=torch.float32, device=self.device)
+            dcount = torch.zeros((b,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gam_rnnt_greedy(self._h, _ptr(encoded), _ptr(enc_len), b, tp, max_symbols, _ptr(ids),
+                                          _ptr(frames), _ptr(counts), _ptr(dump), _ptr(dcount), dump_cap, self._stream())
+        self._check(rc, "gam_rnnt_greedy")
+        if dump_cap > 0:
+            return ids, frames, counts, dump, dcount
+        return ids, frames, counts
+
+    def op_gemm(self, a: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = 0) -> Tensor:
+        a = self._dev(a, torch.float32)
+        w = self._dev(w, torch.float32)
+        bias = None if bias is None else self._dev(bias, torch.float32)
+        m, k = a.shape
+        n = w.shape[0]
+        out = torch.empty((m, n), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gam_op_gemm(self._h, _ptr(a), _ptr(w), _ptr(bias), _ptr(out), m, n, k, act, self._stream())
+        self._check(rc, "gam_op_gemm")
+        return out
+
+    # ------------------------------------------------------------------ profiling
+    def profile_enable(self, on: bool = True) -> None:
+        self._check(self.lib.gam_profile_enable(self._h, int(on)), "gam_profile_enable")
+
+    def profile_read(self) -> Dict[str, Dict[str, float]]:
+        out = {}
+        for i, name in enumerate(_lib.PF_CLASSES):
+            ms, n, work = C.c_double(), C.c_int64(), C.c_double()
+            self._check(self.lib.gam_profile_read(self._h, i, C.byref(ms), C.byref(n), C.byref(work)), "gam_profile_read")
+            out[name] = {"ms": ms.value, "launches": int(n.value), "work": work.value}
+        return out

@@ -1,0 +1,183 @@
+"""Model assembly with the reference's public surface (gigaam/model.py:16-259):
+``GigaAM.forward / embed_audio / prepare_wav``, ``GigaAMASR.transcribe /
+transcribe_longform``.  The four cfg slots are instantiated by class path exactly
+like ``hydra.utils.instantiate`` does in the reference (model.py:24-25,93-94), but
+resolve to the HIP-backed operators of this package, which share ONE library
+handle per model.
+"""
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, List, Mapping, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import decoder as _decoder
+from . import decoding as _decoding
+from . import encoder as _encoder
+from . import preprocess as _preprocess
+from .engine import HipEngine, build_config
+from .preprocess import SAMPLE_RATE, load_audio
+from .types import LongformTranscriptionResult, Segment, TranscriptionResult, Word
+
+LONGFORM_THRESHOLD = 25 * SAMPLE_RATE
+
+_TARGETS = {
+    "FeatureExtractor": _preprocess.FeatureExtractor,
+    "ConformerEncoder": _encoder.ConformerEncoder,
+    "CTCHead": _decoder.CTCHead,
+    "RNNTHead": _decoder.RNNTHead,
+    "CTCGreedyDecoding": _decoding.CTCGreedyDecoding,
+    "RNNTGreedyDecoding": _decoding.RNNTGreedyDecoding,
+}
+
+
+def _node(cfg: Any, key: str) -> Any:
+    return cfg[key] if isinstance(cfg, Mapping) else getattr(cfg, key)
+
+
+def _plain(x: Any) -> Any:
+    if isinstance(x, Mapping):
+        return {k: _plain(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)) or type(x).__name__ == "ListConfig":
+        return [_plain(v) for v in x]
+    return x
+
+
+def instantiate(node: Any) -> Any:
+    """``_target_`` class-path instantiation; 'gigaam.encoder.ConformerEncoder' and
+    'gigaam_amd.encoder.ConformerEncoder' both resolve here."""
+    kw = dict(_plain(node))
+    target = kw.pop("_target_")
+    cls = _TARGETS.get(target.rsplit(".", 1)[-1])
+    if cls is None:
+        raise ValueError(f"no MI355X implementation for {target}")
+    return cls(**kw)
+
+
+class GigaAM(nn.Module):
+    def __init__(self, cfg: Any):
+        super().__init__()
+        self.cfg = cfg
+        self.preprocessor = instantiate(_node(cfg, "preprocessor"))
+        self.encoder = instantiate(_node(cfg, "encoder"))
+
+    def _head_cfg(self) -> Any:
+        return None
+
+    def load_state_dict(self, state_dict: Mapping[str, Tensor], strict: bool = True, assign: bool = False):  # type: ignore[override]
+        """Hand every tensor to the library once (re-laid out there) and share the handle."""
+        self._state = {k: v for k, v in state_dict.items() if isinstance(v, Tensor)}
+        self._build_engine()
+        return nn.modules.module._IncompatibleKeys([], [])
+
+    def _build_engine(self) -> None:
+        dev = self._device
+        if dev.type != "cuda" or getattr(self, "_state", None) is None:
+            return  # built on .to(device)
+        conf = build_config(_node(self.cfg, "preprocessor"), _node(self.cfg, "encoder"), self._head_cfg())
+        eng = HipEngine(conf, self._state, dev)
+        self._state = None
+        for m in (self.preprocessor, self.encoder, getattr(self, "head", None)):
+            if m is not None:
+                m.attach(eng)
+
+    def _apply(self, fn, recurse=True):  # .to(device) / .cuda()
+        out = super()._apply(fn, recurse)
+        self._build_engine()
+        return out
+
+    def forward(self, features: Tensor, feature_lengths: Tensor) -> Tuple[Tensor, Tensor]:
+        """wav [B,L], len [B] -> encoded [B,d_model,T'], len i32 [B]  (model.py:27-37;
+        the reference wraps the encoder in fp16 autocast on GPU, this path stays fp32)."""
+        features, feature_lengths = self.preprocessor(features, feature_lengths)
+        return self.encoder(features, feature_lengths)
+
+    @property
+    def _device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    @property
+    def _dtype(self) -> torch.dtype:
+        return next(self.parameters()).dtype
+
+    def prepare_wav(self, wav_file: str) -> Tuple[Tensor, Tensor]:
+        wav = load_audio(wav_file)
+        wav = wav.to(self._device).to(self._dtype).unsqueeze(0)
+        length = torch.full([1], wav.shape[-1], device=self._device)
+        return wav, length
+
+    def embed_audio(self, wav_file: str) -> Tuple[Tensor, Tensor]:
+        wav, length = self.prepare_wav(wav_file)
+        return self.forward(wav, length)
+
+
+class GigaAMASR(GigaAM):
+    def __init__(self, cfg: Any):
+        super().__init__(cfg)
+        self.head = instantiate(_node(cfg, "head"))
+        self.decoding = instantiate(_node(cfg, "decoding"))
+
+    def _head_cfg(self) -> Any:
+        return _node(self.cfg, "head")
+
+    def _decode(self, encoded: Tensor, encoded_len: Tensor, wav_lens: Tensor,
+                word_timestamps: bool = False) -> List[Tuple[str, Optional[List[Word]]]]:
+        decoded = self.decoding.decode(self.head, encoded, encoded_len)
+        if not word_timestamps:
+            return [(text, None) for text, _, _ in decoded]
+        from .timestamps_utils import compute_frame_shift, frames_to_words
+
+        wl, el = wav_lens.cpu().tolist(), encoded_len.cpu().tolist()
+        out: List[Tuple[str, Optional[List[Word]]]] = []
+        for i, (text, ids, frames) in enumerate(decoded):
+            shift = compute_frame_shift(int(wl[i]), int(el[i]))
+            out.append((text, frames_to_words(self.decoding.tokenizer, ids, frames, shift)))
+        return out
+
+    @torch.inference_mode()
+    def transcribe(self, wav_file: str, word_timestamps: bool = False) -> TranscriptionResult:
+        wav, length = self.prepare_wav(wav_file)
+        if length.item() > LONGFORM_THRESHOLD:
+            raise ValueError("Too long wav file, use 'transcribe_longform' method.")
+        encoded, encoded_len = self.forward(wav, length)
+        text, words = self._decode(encoded, encoded_len, length, word_timestamps)[0]
+        return TranscriptionResult(text=text, words=words)
+
+    @torch.inference_mode()
+    def transcribe_batch(self, wav: Tensor, lengths: Tensor, word_timestamps: bool = False):
+        """Batched twin of ``transcribe`` on an already collated batch (wav [B,L] zero
+        padded, len [B]) -- the unit bench.py and the longform driver iterate."""
+        wav = wav.to(self._device).to(self._dtype)
+        lengths = lengths.to(self._device)
+        encoded, encoded_len = self.forward(wav, lengths)
+        return self._decode(encoded, encoded_len, lengths, word_timestamps)
+
+    @torch.inference_mode()
+    def transcribe_longform(self, wav_file: str, word_timestamps: bool = False, fr_batch_size: int = 16,
+                            fr_num_workers: int = 0, **kwargs: Any) -> LongformTranscriptionResult:
+        """Segment -> zero-padded batches of ``fr_batch_size`` -> transcribe -> stitch
+        (reference model.py:195-259).  The reference segments with pyannote's VAD
+        (gated third-party model, not installable here); pass ``speech_regions=[(s,e),..]``
+        or ``vad=callable(wav, sr) -> regions`` and the reference's own chunk packer
+        (vad_utils.pack_regions) does the rest."""
+        from .vad_utils import segment_audio_file
+
+        segments, boundaries = segment_audio_file(wav_file, SAMPLE_RATE, device=self._device, **kwargs)
+        if not segments:
+            return LongformTranscriptionResult(segments=[])
+        result: List[Segment] = []
+        for i0 in range(0, len(segments), fr_batch_size):
+            chunk = segments[i0:i0 + fr_batch_size]
+            lens = torch.tensor([c.shape[-1] for c in chunk], dtype=torch.int64)
+            wav = torch.zeros(len(chunk), int(lens.max()), dtype=torch.float32)  # utils.AudioDataset.collate layout
+            for j, c in enumerate(chunk):
+                wav[j, : c.shape[-1]] = c
+            for j, (text, words) in enumerate(self.transcribe_batch(wav, lens, word_timestamps)):
+                start, end = boundaries[i0 + j]
+                if word_timestamps:
+                    shifted = [Word(text=w.text, start=round(w.start + start, 3), end=round(w.end + start, 3)) for w in words or []]
+                    result.append(Segment(text=text, start=start, end=end, words=shifted))
+                else:
+                    result.append(Segment(text=text, start=start, end=end))
+        return LongformTranscriptionResult(segments=result)

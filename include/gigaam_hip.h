@@ -1,0 +1,131 @@
+/* gigaam_hip.h -- C ABI of libgigaam_hip.so: the MI355X (gfx950) inference path for
+ * GigaAM's log-mel frontend, Conformer encoder and CTC / RNN-T greedy decoders.
+ *
+ * This is the drop-in boundary of SURVEY.md §8b.  The reference has no FFI of its own
+ * (it is pure Python on torch); what it has is three operator slots instantiated from
+ * the checkpoint config (reference gigaam/model.py:24-25,93-94) with plain-tensor call
+ * contracts.  Each entry point below replaces exactly one of those calls and is what a
+ * ctypes binding on the reference side would load (INTEGRATION.md shows the stub):
+ *
+ *   gam_frontend     <- FeatureExtractor.forward          gigaam/preprocess.py:94-98
+ *   gam_encode       <- ConformerEncoder.forward          gigaam/encoder.py:605-647
+ *   gam_ctc_head     <- CTCHead.forward                   gigaam/decoder.py:18-21
+ *   gam_ctc_greedy   <- CTCGreedyDecoding.decode          gigaam/decoding.py:56-96
+ *   gam_rnnt_greedy  <- RNNTGreedyDecoding.decode         gigaam/decoding.py:128-207
+ *                        (+ RNNTDecoder.predict decoder.py:85-102, RNNTJoint.joint :41-47)
+ *   gam_set_weight   <- nn.Module.load_state_dict         gigaam/__init__.py:185
+ *   gam_create       <- hydra.utils.instantiate(cfg.*)    gigaam/model.py:24-25,93-94
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch types.  All tensor pointers are DEVICE
+ *     pointers unless the parameter says "host".  The caller owns every input/output
+ *     buffer; the library owns weights, position tables and a grow-only workspace.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and performs no host synchronisation, except that a workspace
+ *     growth (first call at a larger shape) allocates.
+ *   - return value 0 = success, negative = error; gam_last_error() has the message.
+ *   - one handle per device; a handle is not thread-safe; distinct handles are independent.
+ *   - arithmetic is fp32 end to end (the parity target is the reference's fp32 CPU path).
+ */
+#ifndef GIGAAM_HIP_H
+#define GIGAAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GAM_ABI_VERSION 1
+
+typedef struct gam_handle gam_handle;
+
+enum { GAM_SUBS_CONV2D = 0, GAM_SUBS_CONV1D = 1 };
+enum { GAM_ATT_ROTARY = 0, GAM_ATT_REL_POS = 1 };
+enum { GAM_NORM_BATCH = 0, GAM_NORM_LAYER = 1 };
+enum { GAM_HEAD_NONE = 0, GAM_HEAD_CTC = 1, GAM_HEAD_RNNT = 2 };
+enum { GAM_DTYPE_F32 = 0, GAM_DTYPE_F16 = 1, GAM_DTYPE_BF16 = 2, GAM_DTYPE_F64 = 3, GAM_DTYPE_I64 = 4 };
+
+/* POD mirror of the four cfg sub-trees of a GigaAM checkpoint. */
+typedef struct gam_config {
+  /* cfg.preprocessor -- FeatureExtractor(sample_rate, features, **kwargs), preprocess.py:60-65 */
+  int32_t sample_rate, n_mels, hop_length, win_length, n_fft, center;
+  /* cfg.encoder -- ConformerEncoder(...), encoder.py:510-526 */
+  int32_t feat_in, n_layers, d_model, subsampling, subs_kernel_size, subsampling_factor;
+  int32_t ff_expansion_factor, self_attention_model, n_heads, pos_emb_max_len;
+  int32_t conv_norm_type, conv_kernel_size;
+  /* cfg.head -- CTCHead(feat_in, num_classes) decoder.py:12-16 | RNNTHead(decoder, joint) :146-149 */
+  int32_t head_type, num_classes, pred_hidden, pred_rnn_layers, joint_hidden;
+} gam_config;
+
+int gam_abi_version(void);
+
+/* Construct the operators for one device.  Weights arrive through gam_set_weight. */
+int gam_create(const gam_config* cfg, int device_id, gam_handle** out);
+void gam_destroy(gam_handle* h);
+
+/* Stage one state_dict entry (HOST pointer, copied).  `key` is the reference's
+ * state_dict key ("encoder.layers.0.self_attn.linear_q.weight", ...).
+ * Unknown keys are accepted and ignored (e.g. num_batches_tracked). */
+int gam_set_weight(gam_handle* h, const char* key, const void* host_ptr, int dtype,
+                   const int64_t* shape, int ndim);
+
+/* Validate the key set, re-lay weights for the kernels (fused q|k, channels-last conv
+ * taps, folded BatchNorm, DFT basis, rotary table, LSTM input table) and upload. */
+int gam_finalize(gam_handle* h);
+
+/* Shape helpers (host arithmetic): mel frames for L samples (preprocess.py:78-92) and
+ * encoder frames for T mel frames (encoder.py:77-90). */
+int64_t gam_feat_frames(const gam_handle* h, int64_t n_samples);
+int64_t gam_enc_frames(const gam_handle* h, int64_t n_feat_frames);
+
+/* FeatureExtractor.forward: wav f32 [B,L], len i64 [B] -> feat f32 [B,n_mels,T], feat_len i64 [B];
+ * T = gam_feat_frames(L). */
+int gam_frontend(gam_handle* h, const float* wav, const int64_t* wav_len, int B, int64_t L,
+                 float* feat, int64_t* feat_len, void* stream);
+
+/* ConformerEncoder.forward: feat f32 [B,feat_in,T], feat_len i64 [B] ->
+ * encoded f32 [B,d_model,T'], enc_len i32 [B]; T' = gam_enc_frames(T). */
+int gam_encode(gam_handle* h, const float* feat, const int64_t* feat_len, int B, int64_t T,
+               float* encoded, int32_t* enc_len, void* stream);
+
+/* Test hook: as gam_encode but stops after `n_layers_run` Conformer layers (0 = after
+ * pre_encode, <0 = all) and, if tokens_out != NULL, also writes the token-major
+ * activations f32 [B,T',d_model] at that point. */
+int gam_encode_ex(gam_handle* h, const float* feat, const int64_t* feat_len, int B, int64_t T,
+                  float* encoded, int32_t* enc_len, int n_layers_run, float* tokens_out, void* stream);
+
+/* CTCHead.forward: encoded f32 [B,d_model,T'] -> log_probs f32 [B,T',V]. */
+int gam_ctc_head(gam_handle* h, const float* encoded, int B, int64_t Tp, float* log_probs, void* stream);
+
+/* CTCGreedyDecoding.decode: -> ids i32 [B,T'], frames i32 [B,T'] (first counts[b] valid), counts i32 [B]. */
+int gam_ctc_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len, int B, int64_t Tp,
+                   int32_t* ids, int32_t* frames, int32_t* counts, void* stream);
+
+/* RNNTGreedyDecoding.decode: ids/frames i32 [B, T'*max_symbols], counts i32 [B].
+ * Optional dump of the log-softmax of every joint evaluation, in order, per utterance:
+ * logits_dump f32 [B,dump_cap,V] (may be NULL), dump_count i32 [B] (may be NULL). */
+int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len, int B, int64_t Tp,
+                    int max_symbols, int32_t* ids, int32_t* frames, int32_t* counts,
+                    float* logits_dump, int32_t* dump_count, int dump_cap, void* stream);
+
+/* Raw fp32 GEMM entry for kernel-level tests and the roofline bench:
+ * C[M,N] = act(A[M,K] . W[N,K]^T + bias) (act: 0 none, 1 SiLU, 2 ReLU); K % 32 == 0. */
+int gam_op_gemm(gam_handle* h, const float* A, const float* W, const float* bias, float* C,
+                int M, int N, int K, int act, void* stream);
+
+/* Per-kernel-class HIP-event timing on the launch stream (bench.py's roofline leg).
+ * gam_profile_enable(h,1) starts collecting; gam_profile_read synchronises the events and
+ * returns, for class `cls`, the summed milliseconds, launch count and algorithmic work
+ * (FLOP for GEMM/attention classes, bytes for the HBM-bound classes); it then resets. */
+enum { GAM_PF_GEMM = 0, GAM_PF_CONV2 = 1, GAM_PF_ATTN = 2, GAM_PF_NORM = 3, GAM_PF_CONVMOD = 4,
+       GAM_PF_STEM = 5, GAM_PF_FRONTEND = 6, GAM_PF_DECODE = 7, GAM_PF_MISC = 8, GAM_PF_NCLASS = 9 };
+int gam_profile_enable(gam_handle* h, int on);
+int gam_profile_read(gam_handle* h, int cls, double* ms, int64_t* launches, double* work);
+
+const char* gam_last_error(const gam_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GIGAAM_HIP_H */

@@ -1,0 +1,172 @@
+"""GPU: the HIP path (through the C ABI) against the CPU oracle and the reference's
+golden vectors, on the same seeded inputs.  Tolerances are in tests/common.py."""
+import numpy as np
+import pytest
+import torch
+
+from common import (CASES, TOL_ENC, TOL_FEAT, TOL_LOGP, load_case, oracle_features, ragged_from_device,
+                    split_ragged, valid_mask)
+from oracle import gigaam_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SUPPORTED = [c for c in CASES if not c.startswith("v1_")]  # rel_pos attention: see DESIGN.md
+
+
+def _engine(ck):
+    from gigaam_amd.engine import HipEngine, build_config
+    cfg = ck["cfg"]
+    return HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], cfg.get("head")), ck["state_dict"], torch.device("cuda:0"))
+
+
+def test_gemm_kernel_shapes_and_epilogues():
+    from gigaam_amd import synth
+    from gigaam_amd.engine import HipEngine, build_config
+    cfg = synth.model_cfg("v2_ctc")
+    eng = HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], None), {}, torch.device("cuda:0"))
+    g = torch.Generator().manual_seed(0)
+    # asymmetric operands, ragged M/N edges, all activations (transposes / layout slips cannot hide)
+    for (m, n, k, act) in [(128, 128, 32, 0), (300, 200, 64, 0), (1000, 768, 768, 1), (257, 34, 768, 0), (515, 1536, 96, 2), (1, 1, 32, 0)]:
+        a = torch.randn(m, k, generator=g)
+        w = torch.randn(n, k, generator=g) / k ** 0.5
+        b = torch.randn(n, generator=g)
+        ref = a.double() @ w.double().t() + b.double()
+        ref = ref * torch.sigmoid(ref) if act == 1 else (torch.relu(ref) if act == 2 else ref)
+        out = eng.op_gemm(a, w, b, act).cpu().double()
+        assert float((out - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), (m, n, k, act)
+    eye = torch.eye(64)
+    w = torch.arange(96 * 64, dtype=torch.float32).reshape(96, 64) / 100.0
+    assert torch.equal(eng.op_gemm(eye, w).cpu(), w.t().contiguous())  # A = I, asymmetric W: exact
+
+
+@pytest.mark.parametrize("case", SUPPORTED)
+def test_frontend_matches_oracle(case):
+    ck, wav, wlen, gold = load_case(case)
+    eng = _engine(ck)
+    feat_o, flen_o = oracle_features(ck, wav, wlen)
+    feat, flen = eng.frontend(wav, wlen)
+    assert feat.shape == feat_o.shape and flen.dtype == torch.int64 and flen.cpu().tolist() == flen_o.tolist()
+    fm = valid_mask(feat_o.shape[2], flen_o)[:, None, :]
+    assert float(((feat.cpu() - feat_o) * fm).abs().max()) < TOL_FEAT
+    np.testing.assert_allclose(feat.cpu()[:, ::7, ::13].numpy(), gold["feat_probe"], atol=TOL_FEAT)
+
+
+@pytest.mark.parametrize("case", SUPPORTED)
+def test_encoder_matches_reference_golden(case):
+    ck, wav, wlen, gold = load_case(case)
+    eng = _engine(ck)
+    feat_o, flen_o = oracle_features(ck, wav, wlen)
+    enc, elen = eng.encode(feat_o, flen_o)
+    assert elen.dtype == torch.int32 and elen.cpu().tolist() == gold["enc_len"].tolist()
+    assert tuple(enc.shape) == gold["encoded"].shape
+    vm = valid_mask(enc.shape[2], gold["enc_len"])
+    assert bool(torch.isfinite(enc).all())  # padded rows are don't-care but must stay finite
+    assert float(((enc.cpu() - torch.from_numpy(gold["encoded"])) * vm[:, None, :]).abs().max()) < TOL_ENC
+    _, _, tok = eng.encode(feat_o, flen_o, n_layers_run=0, want_tokens=True)
+    assert float(((tok.cpu() - torch.from_numpy(gold["pre_encode"])) * vm[:, :, None]).abs().max()) < TOL_ENC
+
+
+@pytest.mark.parametrize("case", [c for c in SUPPORTED if "ctc" in c])
+def test_ctc_bit_exact_ids_and_frames(case):
+    ck, wav, wlen, gold = load_case(case)
+    eng = _engine(ck)
+    ref = split_ragged(gold["ids"], gold["frames"], gold["counts"].tolist())
+    enc_ref = torch.from_numpy(gold["encoded"])
+    elen_ref = torch.from_numpy(gold["enc_len"])
+    lp = eng.ctc_head(enc_ref).cpu()
+    vm = valid_mask(lp.shape[1], gold["enc_len"])
+    assert float(((lp - torch.from_numpy(gold["log_probs"])) * vm[:, :, None]).abs().max()) < TOL_LOGP
+    # decoder alone on the reference's encoder output
+    assert ragged_from_device(*eng.ctc_greedy(enc_ref, elen_ref)) == ref
+    # whole path wav -> ids on the GPU
+    feat, flen = eng.frontend(wav, wlen)
+    enc, elen = eng.encode(feat, flen)
+    assert ragged_from_device(*eng.ctc_greedy(enc, elen)) == ref
+
+
+@pytest.mark.parametrize("case", [c for c in SUPPORTED if "rnnt" in c])
+def test_rnnt_ids_frames_and_logits(case):
+    ck, wav, wlen, gold = load_case(case)
+    cfg, sd = ck["cfg"], ck["state_dict"]
+    eng = _engine(ck)
+    ms = cfg["decoding"]["max_symbols_per_step"]
+    ref = split_ragged(gold["ids"], gold["frames"], gold["counts"].tolist())
+    enc_ref = torch.from_numpy(gold["encoded"])
+    elen_ref = torch.from_numpy(gold["enc_len"])
+    trace = []
+    with torch.no_grad():
+        assert O.rnnt_greedy(sd, enc_ref, elen_ref, ms, trace=trace) == ref
+    b = enc_ref.shape[0]
+    per = [[t for t in trace if t[0] == i] for i in range(b)]
+    cap = max(len(p) for p in per)
+    ids, frames, counts, dump, dcount = eng.rnnt_greedy(enc_ref, elen_ref, ms, dump_cap=cap)
+    got = ragged_from_device(ids, frames, counts)
+    # joint log-probs of every step, in order (north_star: within 1e-3 fp32)
+    margins = [float(t[2].topk(2).values[0] - t[2].topk(2).values[1]) for t in trace]
+    if got == ref:
+        assert dcount.cpu().tolist() == [len(p) for p in per]
+        for i in range(b):
+            want = torch.stack([t[2] for t in per[i]])
+            assert float((dump[i, : want.shape[0]].cpu() - want).abs().max()) < TOL_LOGP
+    else:  # only a near-tie (oracle top-1/top-2 margin below fp32 noise) may differ
+        assert min(margins) < 1e-4, (min(margins), [len(a) for a, _ in got], [len(a) for a, _ in ref])
+    assert got == ref or min(margins) < 1e-4
+    # whole path
+    feat, flen = eng.frontend(wav, wlen)
+    enc, elen = eng.encode(feat, flen)
+    got2 = ragged_from_device(*eng.rnnt_greedy(enc, elen, ms))
+    assert got2 == ref or min(margins) < 1e-3
+
+
+def test_batched_equals_single_and_edge_lengths():
+    """reference tests/test_batching.py:70-140: batched == single on valid frames; very short inputs run."""
+    ck, wav, wlen, _ = load_case("v2_ctc_l2")
+    eng = _engine(ck)
+    feat, flen = eng.frontend(wav, wlen)
+    enc, elen = eng.encode(feat, flen)
+    for i in range(wav.shape[0]):
+        n = int(wlen[i])
+        f1, l1 = eng.frontend(wav[i:i + 1, :n], wlen[i:i + 1])
+        e1, el1 = eng.encode(f1, l1)
+        t = int(el1[0])
+        assert int(elen[i]) == t
+        assert float((enc[i, :, :t] - e1[0, :, :t]).abs().max()) < 0.03  # the reference's own atol
+    for n in (3200, 5000, 8000, 16000):  # 0.2 s .. 1 s
+        w, l = wav[:2, :n].contiguous(), torch.tensor([n, n - 7])
+        f, fl = eng.frontend(w, l)
+        e, el = eng.encode(f, fl)
+        ids, frames, counts = eng.ctc_greedy(e, el)
+        assert bool(torch.isfinite(e).all()) and int(counts.max()) <= e.shape[2]
+    # zero-length utterance inside a batch: no tokens, nothing crashes
+    l0 = torch.tensor([int(wlen[0]), 0, int(wlen[2])])
+    f, fl = eng.frontend(wav, l0)
+    e, el = eng.encode(f, torch.tensor([int(fl[0]), 0, int(fl[2])]))
+    ids, frames, counts = eng.ctc_greedy(e, el)
+    assert int(el[1]) == 0 and int(counts[1]) == 0 and bool(torch.isfinite(e).all())
+
+
+def test_model_api_transcribe(tmp_path):
+    """load_model()/transcribe()/embed_audio() surface on a PCM16 wav (config 1 plumbing)."""
+    import wave
+    import gigaam_amd
+    from gigaam_amd import synth
+    ck = synth.make_checkpoint("v2_ctc", seed=1, n_layers=2)
+    path = str(tmp_path / "model.ckpt")
+    torch.save(ck, path)
+    model = gigaam_amd.load_model(path, device="cuda:0")
+    wav, wlen = synth.synth_audio(1, 5.0, seed=0)
+    pcm = (wav[0].numpy() * 32768.0).round().clip(-32768, 32767).astype(np.int16)
+    wpath = str(tmp_path / "clip.wav")
+    with wave.open(wpath, "wb") as wf:
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000); wf.writeframes(pcm.tobytes())
+    res = model.transcribe(wpath, word_timestamps=True)
+    x = torch.from_numpy(pcm.astype(np.float32) / 32768.0)[None]
+    with torch.no_grad():
+        dec, enc_o, elen_o = O.transcribe_ids(ck, x, torch.tensor([x.shape[1]]))
+    text = "".join(synth.CHAR_VOCAB[i] for i in dec[0][0])
+    assert str(res) == text and res.words is not None
+    enc, elen = model.embed_audio(wpath)
+    assert enc.shape == enc_o.shape and int(elen[0]) == int(elen_o[0])
+    assert float((enc.cpu() - enc_o).abs().max()) < 1e-3
+    out = model.transcribe_longform(wpath, speech_regions=[(0.0, 2.4), (2.6, 5.0)], min_duration=1.0, max_duration=2.5)
+    assert len(out) == 2 and all(isinstance(s.text, str) for s in out)

@@ -1,0 +1,70 @@
+"""CPU: the oracle restatement reproduces the REFERENCE's committed outputs
+(tests/golden/*.npz were produced by the reference's own modules, see make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from common import CASES, load_case, oracle_features, split_ragged, valid_mask
+from oracle import gigaam_oracle as O
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_oracle_matches_reference_golden(case):
+    torch.set_num_threads(8)
+    ck, wav, wlen, gold = load_case(case)
+    cfg, sd = ck["cfg"], ck["state_dict"]
+    feat, flen = oracle_features(ck, wav, wlen)
+    assert flen.tolist() == gold["feat_len"].tolist()
+    np.testing.assert_allclose(feat[:, ::7, ::13].numpy(), gold["feat_probe"], atol=1e-5)
+    stages = {}
+    with torch.no_grad():
+        enc, elen = O.encoder_forward(sd, cfg["encoder"], feat, flen, stages=stages)
+    assert elen.dtype == torch.int32 and elen.tolist() == gold["enc_len"].tolist()
+    vm = valid_mask(enc.shape[2], elen)
+    assert float(((stages["pre_encode"] - torch.from_numpy(gold["pre_encode"])) * vm[:, :, None]).abs().max()) < 2e-5
+    assert float(((enc - torch.from_numpy(gold["encoded"])) * vm[:, None, :]).abs().max()) < 2e-5
+    ref = split_ragged(gold["ids"], gold["frames"], gold["counts"].tolist())
+    enc_ref = torch.from_numpy(gold["encoded"])
+    with torch.no_grad():
+        if "log_probs" in gold:
+            lp = O.ctc_log_probs(sd, enc_ref)
+            assert float((lp - torch.from_numpy(gold["log_probs"])).abs().max()) < 2e-5
+            got = O.ctc_greedy(lp, elen)
+        else:
+            trace = []
+            got = O.rnnt_greedy(sd, enc_ref, elen, cfg["decoding"]["max_symbols_per_step"], trace=trace)
+            first = torch.stack([t[2] for t in trace[:64]])
+            assert float((first - torch.from_numpy(gold["trace_first"])).abs().max()) < 2e-5
+    assert got == ref
+
+
+def test_frontend_known_answers():
+    """a1 is parity-unpinned (no torchaudio here): analytic checks of the restatement."""
+    from gigaam_amd import synth
+    cfg = synth.model_cfg("v2_ctc")["preprocessor"]
+    win = torch.from_numpy(synth.hann_window_periodic(400))
+    fb = torch.from_numpy(synth.mel_filterbank_htk(201, 64, 16000))
+    # frame-count formula (reference preprocess.py:78-92)
+    for n in (3200, 16000, 80000, 80001, 320000):
+        wav = torch.zeros(1, n)
+        feat, flen = O.log_mel(wav, torch.tensor([n]), cfg, win, fb)
+        assert feat.shape == (1, 64, n // 160 + 1) and int(flen) == n // 160 + 1
+        assert torch.allclose(feat, torch.full_like(feat, float(np.log(1e-9))))  # silence -> clamp floor
+    # pure tone at an exact bin (k=40 -> 1600 Hz): energy sits in the mel bands around it
+    t = torch.arange(16000) / 16000.0
+    feat, _ = O.log_mel(torch.sin(2 * np.pi * 1600.0 * t)[None], torch.tensor([16000]), cfg, win, fb)
+    mid = feat[0, :, 50]
+    band = int(mid.argmax())
+    assert fb[40, band] > 0 and fb[40].argmax() == band
+    # Hann-windowed bin-centred tone: |X_k|^2 = (N/4)^2 and (N/8)^2 in the two neighbours
+    expect = 100.0 ** 2 * float(fb[40, band]) + 50.0 ** 2 * float(fb[39, band] + fb[41, band])
+    assert abs(float(mid.max()) - float(np.log(expect))) < 1e-3
+    # filterbank: triangles cover every non-edge bin, all weights in [0, 1]
+    assert float(fb.min()) >= 0 and float(fb.max()) <= 1.0
+    assert bool((fb[1:-1].sum(dim=1) > 0).all())
+    # v3 frontend: center=False, 320/160
+    cfg3 = synth.model_cfg("v3_ctc")["preprocessor"]
+    feat, flen = O.log_mel(torch.zeros(1, 16000), torch.tensor([16000]), cfg3,
+                           torch.from_numpy(synth.hann_window_periodic(320)),
+                           torch.from_numpy(synth.mel_filterbank_htk(161, 64, 16000)))
+    assert feat.shape[2] == (16000 - 320) // 160 + 1 == int(flen)
