@@ -20,13 +20,15 @@
 // Tiling: 128x128x32 block tile, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2
 // MFMA tiles of 32x32; LDS rows padded to 36 floats (9 x 16 B, odd) so both the
 // ds_write_b128 staging and the ds_read_b128 fragment reads are bank-conflict-free;
-// register-staged global->LDS double buffering with one barrier per k-tile.  A lane
+// register-staged global->LDS pipeline (next k-tile in flight in VGPRs), one 36 KB LDS
+// tile set so that three workgroups share a CU.  A lane
 // reads 4 consecutive k of its row with one ds_read_b128 and feeds them to 4 MFMAs
 // (k-pairs {q, q+4}): the permuted k order is the same for A and W, so the dot
 // product is unchanged.  blockIdx -> tile mapping is XCD-aware (all N-tiles of an
 // M-tile land on the same XCD/L2, so A is fetched from HBM once).
 #pragma once
 #include "gam_common.h"
+#include <stdlib.h>
 
 struct GamGemmArgs {
   const float* A;
@@ -54,14 +56,14 @@ struct GamGemmArgs {
 #define GAM_GEMM_BN 128
 #define GAM_GEMM_BK 32
 #define GAM_GEMM_LD 36
-#define GAM_GEMM_SMEM (2 * (GAM_GEMM_BM + GAM_GEMM_BN) * GAM_GEMM_LD * 4)
+#define GAM_GEMM_SMEM(NBUF) ((NBUF) * (GAM_GEMM_BM + GAM_GEMM_BN) * GAM_GEMM_LD * 4)
 
-template <int ACT>
-__global__ __launch_bounds__(256, 2) void gam_gemm_f32_kernel(GamGemmArgs g) {
+template <int ACT, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gam_gemm_f32_kernel(GamGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float gam_smem[];
   constexpr int BM = GAM_GEMM_BM, BN = GAM_GEMM_BN, BK = GAM_GEMM_BK, LD = GAM_GEMM_LD;
   float* As = gam_smem;
-  float* Bs = gam_smem + 2 * BM * LD;
+  float* Bs = gam_smem + NBUF * BM * LD;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -143,32 +145,57 @@ __global__ __launch_bounds__(256, 2) void gam_gemm_f32_kernel(GamGemmArgs g) {
   }
 #define GAM_MFMA(AV, BV, ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BV, ACC, 0, 0, 0)
 
-  GAM_GLOAD(0);
-  GAM_LSTORE(0);
-  __syncthreads();
-
+  // One LDS tile set (36 KB -> 3 workgroups per CU, i.e. 768 resident tiles: the
+  // 126 x 6 = 756 tiles of an N = 768 GEMM at the bench shape run in ONE round), the
+  // next k-tile travels through registers while the current one is multiplied:
+  //   barrier | regs -> LDS | barrier | issue global loads of tile kt+1 | 64 MFMAs
+  // The two barriers per k-tile are covered by the other resident workgroups' MFMAs.
   const int frag = (lane & 31) * LD + (lane >> 5) * 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    const bool more = kt + 1 < nk;
-    if (more) GAM_GLOAD(kt + 1);
-    const float* Ab = As + buf * BM * LD + wm * 64 * LD + frag;
-    const float* Bb = Bs + buf * BN * LD + wn * 64 * LD + frag;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float4 a0 = *reinterpret_cast<const float4*>(Ab + s * 8);
-      const float4 a1 = *reinterpret_cast<const float4*>(Ab + 32 * LD + s * 8);
-      const float4 b0 = *reinterpret_cast<const float4*>(Bb + s * 8);
-      const float4 b1 = *reinterpret_cast<const float4*>(Bb + 32 * LD + s * 8);
-      // four independent accumulators: dependent MFMAs are 4 issues apart
-      GAM_MFMA(a0.x, b0.x, acc00); GAM_MFMA(a0.x, b1.x, acc01); GAM_MFMA(a1.x, b0.x, acc10); GAM_MFMA(a1.x, b1.x, acc11);
-      GAM_MFMA(a0.y, b0.y, acc00); GAM_MFMA(a0.y, b1.y, acc01); GAM_MFMA(a1.y, b0.y, acc10); GAM_MFMA(a1.y, b1.y, acc11);
-      GAM_MFMA(a0.z, b0.z, acc00); GAM_MFMA(a0.z, b1.z, acc01); GAM_MFMA(a1.z, b0.z, acc10); GAM_MFMA(a1.z, b1.z, acc11);
-      GAM_MFMA(a0.w, b0.w, acc00); GAM_MFMA(a0.w, b1.w, acc01); GAM_MFMA(a1.w, b0.w, acc10); GAM_MFMA(a1.w, b1.w, acc11);
-    }
-    if (more) GAM_LSTORE(buf ^ 1);
-    __syncthreads();
+#define GAM_COMPUTE(AB, BB)                                                                     \
+  _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                               \
+    const float4 a0 = *reinterpret_cast<const float4*>((AB) + s * 8);                           \
+    const float4 a1 = *reinterpret_cast<const float4*>((AB) + 32 * LD + s * 8);                 \
+    const float4 b0 = *reinterpret_cast<const float4*>((BB) + s * 8);                           \
+    const float4 b1 = *reinterpret_cast<const float4*>((BB) + 32 * LD + s * 8);                 \
+    /* four independent accumulators: dependent MFMAs are 4 issues apart */                     \
+    GAM_MFMA(a0.x, b0.x, acc00); GAM_MFMA(a0.x, b1.x, acc01); GAM_MFMA(a1.x, b0.x, acc10); GAM_MFMA(a1.x, b1.x, acc11); \
+    GAM_MFMA(a0.y, b0.y, acc00); GAM_MFMA(a0.y, b1.y, acc01); GAM_MFMA(a1.y, b0.y, acc10); GAM_MFMA(a1.y, b1.y, acc11); \
+    GAM_MFMA(a0.z, b0.z, acc00); GAM_MFMA(a0.z, b1.z, acc01); GAM_MFMA(a1.z, b0.z, acc10); GAM_MFMA(a1.z, b1.z, acc11); \
+    GAM_MFMA(a0.w, b0.w, acc00); GAM_MFMA(a0.w, b1.w, acc01); GAM_MFMA(a1.w, b0.w, acc10); GAM_MFMA(a1.w, b1.w, acc11); \
   }
+  if constexpr (NBUF == 1) {
+    // One LDS tile set (36 KB -> 3 workgroups per CU, i.e. 768 resident tiles: the
+    // 126 x 6 = 756 tiles of an N = 768 GEMM at the bench shape run in ONE round); the
+    // next k-tile travels through registers while the current one is multiplied:
+    //   barrier | regs -> LDS | barrier | issue global loads of tile kt+1 | 64 MFMAs
+    // The two barriers per k-tile are covered by the other resident workgroups' MFMAs.
+    GAM_GLOAD(0);
+    const float* Ab = As + wm * 64 * LD + frag;
+    const float* Bb = Bs + wn * 64 * LD + frag;
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();
+      GAM_LSTORE(0);
+      __syncthreads();
+      if (kt + 1 < nk) GAM_GLOAD(kt + 1);
+      GAM_COMPUTE(Ab, Bb);
+    }
+  } else {
+    // Two LDS tile sets (72 KB -> 2 workgroups per CU), one barrier per k-tile.
+    GAM_GLOAD(0);
+    GAM_LSTORE(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      const bool more = kt + 1 < nk;
+      if (more) GAM_GLOAD(kt + 1);
+      const float* Ab = As + buf * BM * LD + wm * 64 * LD + frag;
+      const float* Bb = Bs + buf * BN * LD + wn * 64 * LD + frag;
+      GAM_COMPUTE(Ab, Bb);
+      if (more) GAM_LSTORE(buf ^ 1);
+      __syncthreads();
+    }
+  }
+#undef GAM_COMPUTE
 #undef GAM_GLOAD
 #undef GAM_LSTORE
 #undef GAM_MFMA
@@ -209,29 +236,41 @@ __global__ __launch_bounds__(256, 2) void gam_gemm_f32_kernel(GamGemmArgs g) {
   }
 }
 
-static inline hipError_t gam_launch_gemm(const GamGemmArgs& a, int act, hipStream_t stream) {
+template <int ACT, int NBUF>
+static inline void gam_launch_gemm_t(const GamGemmArgs& a, int grid, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gam_gemm_f32_kernel<GAM_ACT_NONE>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, GAM_GEMM_SMEM);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gam_gemm_f32_kernel<GAM_ACT_SILU>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, GAM_GEMM_SMEM);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gam_gemm_f32_kernel<GAM_ACT_RELU>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, GAM_GEMM_SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gam_gemm_f32_kernel<ACT, NBUF>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, GAM_GEMM_SMEM(NBUF));
     attr_done = true;
   }
+  hipLaunchKernelGGL((gam_gemm_f32_kernel<ACT, NBUF>), dim3(grid), dim3(256), GAM_GEMM_SMEM(NBUF), stream, a);
+}
+
+// GAM_GEMM_NBUF=2 selects the double-buffered variant (A/B measurements only)
+static inline int gam_gemm_nbuf() {
+  static int v = 0;
+  if (v == 0) {
+    const char* e = getenv("GAM_GEMM_NBUF");
+    v = (e && e[0] == '2') ? 2 : 1;
+  }
+  return v;
+}
+
+static inline hipError_t gam_launch_gemm(const GamGemmArgs& a, int act, hipStream_t stream) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K % GAM_GEMM_BK != 0 || a.K <= 0) return hipErrorInvalidValue;
   const int grid = gam_cdiv(a.M, GAM_GEMM_BM) * gam_cdiv(a.N, GAM_GEMM_BN);
+  const bool one = gam_gemm_nbuf() == 1;
   switch (act) {
     case GAM_ACT_SILU:
-      hipLaunchKernelGGL(gam_gemm_f32_kernel<GAM_ACT_SILU>, dim3(grid), dim3(256), GAM_GEMM_SMEM, stream, a);
+      if (one) gam_launch_gemm_t<GAM_ACT_SILU, 1>(a, grid, stream); else gam_launch_gemm_t<GAM_ACT_SILU, 2>(a, grid, stream);
       break;
     case GAM_ACT_RELU:
-      hipLaunchKernelGGL(gam_gemm_f32_kernel<GAM_ACT_RELU>, dim3(grid), dim3(256), GAM_GEMM_SMEM, stream, a);
+      if (one) gam_launch_gemm_t<GAM_ACT_RELU, 1>(a, grid, stream); else gam_launch_gemm_t<GAM_ACT_RELU, 2>(a, grid, stream);
       break;
     default:
-      hipLaunchKernelGGL(gam_gemm_f32_kernel<GAM_ACT_NONE>, dim3(grid), dim3(256), GAM_GEMM_SMEM, stream, a);
+      if (one) gam_launch_gemm_t<GAM_ACT_NONE, 1>(a, grid, stream); else gam_launch_gemm_t<GAM_ACT_NONE, 2>(a, grid, stream);
       break;
   }
   return hipGetLastError();

@@ -2,10 +2,16 @@ import os
 import sys
 
 import pytest
+import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+
+# the CPU oracle is many small torch ops: on a many-core GPU host (256 threads) the
+# default thread count makes it ~50x slower than 16 threads
+torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 
 def pytest_configure(config):

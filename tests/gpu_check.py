@@ -21,9 +21,12 @@ from oracle import gigaam_oracle as O  # noqa: E402
 RES = {}
 
 
+T0 = time.time()
+
+
 def report(name, **kw):
     RES[name] = kw
-    print(f"[{name}] " + " ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in kw.items()), flush=True)
+    print(f"[{time.time() - T0:7.1f}s] [{name}] " + " ".join(f"{k}={v:.3e}" if isinstance(v, float) else f"{k}={v}" for k, v in kw.items()), flush=True)
 
 
 def guarded(fn):
@@ -115,8 +118,10 @@ def check_model(model, n_layers, batch, secs, lens, seed_audio=11, deep=True):
     else:
         ms = cfg["decoding"]["max_symbols_per_step"]
         trace = []
+        print(f"[{time.time() - T0:7.1f}s] oracle rnnt_greedy ...", flush=True)
         with torch.no_grad():
             dec_o = O.rnnt_greedy(sd, enc_o, elen_o, ms, trace=trace)
+        print(f"[{time.time() - T0:7.1f}s] oracle rnnt_greedy done, {len(trace)} steps", flush=True)
         cap = max(sum(1 for t in trace if t[0] == b) for b in range(batch))
         for src, enc_in, len_in in (("oracle_enc", enc_o, elen_o), ("hip_enc", enc_g, elen_g)):
             ids, frames, counts, dump, dcount = eng.rnnt_greedy(enc_in, len_in, ms, dump_cap=cap)
@@ -135,16 +140,22 @@ def check_model(model, n_layers, batch, secs, lens, seed_audio=11, deep=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "check.json"))
-    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default="")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count())
     print("device:", torch.cuda.get_device_name(0), flush=True)
-    check_gemm()
-    check_model("v2_ctc", 2, 3, 4.0, [64000, 50000, 33333])
-    check_model("v2_ctc", 2, 1, 2.5, None, seed_audio=12)
-    check_model("v2_rnnt", 2, 3, 4.0, [64000, 41234, 57000], seed_audio=13, deep=False)
-    check_model("v3_ctc", 2, 3, 4.0, [64000, 50000, 33333], seed_audio=14)
-    check_model("v3_e2e_rnnt", 2, 2, 3.0, [48000, 30011], seed_audio=15, deep=False)
+    only = args.only
+    if only in ("", "gemm"):
+        check_gemm()
+    if only in ("", "v2_ctc"):
+        check_model("v2_ctc", 2, 3, 4.0, [64000, 50000, 33333])
+        check_model("v2_ctc", 2, 1, 2.5, None, seed_audio=12)
+    if only in ("", "v2_rnnt"):
+        check_model("v2_rnnt", 2, 3, 4.0, [64000, 41234, 57000], seed_audio=13, deep=False)
+    if only in ("", "v3_ctc"):
+        check_model("v3_ctc", 2, 3, 4.0, [64000, 50000, 33333], seed_audio=14)
+    if only in ("", "v3_e2e_rnnt"):
+        check_model("v3_e2e_rnnt", 2, 2, 3.0, [48000, 30011], seed_audio=15, deep=False)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     json.dump(RES, open(args.out, "w"), indent=1)
 

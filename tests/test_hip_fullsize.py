@@ -37,13 +37,12 @@ def test_fullsize_shapes_determinism_and_padding_invariance(full_model):
         assert frames == sorted(set(frames)) and (not frames or frames[-1] < n)
         assert all(a != b or fb > fa + 1 for a, b, fa, fb in zip(ids, ids[1:], frames, frames[1:]))
     assert sum(len(i) for i, _ in out) > 100  # non-degenerate decode
-    # batch composition / padding invariance: utterance 5 alone == inside the batch
-    n = int(wlen[5])
-    f1, l1 = eng.frontend(wav[5:6, :n].contiguous(), wlen[5:6])
-    e1, el1 = eng.encode(f1, l1)
+    # batch composition / padding invariance: utterance 5's features alone == inside the batch
+    tf = int(flen[5])
+    e1, el1 = eng.encode(feat[5:6, :, :tf].contiguous(), flen[5:6])
     t = int(el1[0])
     assert t == int(elen[5])
-    assert float((enc[5, :, :t] - e1[0, :, :t]).abs().max()) < 0.03
+    assert float((enc[5, :, :t] - e1[0, :, :t]).abs().max()) < 1e-3
     # permutation equivariance over the batch dimension
     perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4])
     encp, elenp = eng.encode(*eng.frontend(wav[perm].contiguous(), wlen[perm]))
@@ -58,7 +57,6 @@ def test_fullsize_matches_oracle_on_one_utterance(full_model):
     from oracle import gigaam_oracle as O
     eng, wav, wlen = full_model
     ck = synth.make_checkpoint("v2_ctc", seed=0)
-    torch.set_num_threads(torch.get_num_threads())
     with torch.no_grad():
         dec_o, enc_o, elen_o = O.transcribe_ids(ck, wav[:1], wlen[:1])
         lp = O.ctc_log_probs(ck["state_dict"], enc_o)
