@@ -35,6 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+F16_MFMA_PEAK_TFLOPS = 2500.0   # same guide: dense fp16/bf16 MFMA (32x32x16)
 FLOP_PER_UTT_20S_V2 = 325.9e9   # SURVEY.md §8d / BASELINE.md §3
 
 
@@ -118,6 +119,8 @@ def main():
     ap.add_argument("--layers", type=int, default=-1, help="debug only: fewer layers INVALIDATES the number")
     ap.add_argument("--cpu-utts", type=int, default=8, help="utterances in the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
+    ap.add_argument("--gemm", default="f16x3", choices=["f16x3", "f32"],
+                    help="dense-contraction arithmetic: split-fp16 MFMA (fp32-equivalent, default) or exact fp32 MFMA")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -139,6 +142,7 @@ def main():
     ckpt = synth.make_checkpoint(args.model, seed=0, **over)
     model = gigaam_amd.model_from_checkpoint(ckpt, dev)
     eng = model.encoder.engine
+    eng.set_gemm_mode(args.gemm)
     is_ctc = ckpt["cfg"]["head"]["_target_"].endswith("CTCHead")
     max_sym = ckpt["cfg"]["decoding"].get("max_symbols_per_step", 10)
 
@@ -185,7 +189,8 @@ def main():
         "metric": f"RTFx {args.model} batch{args.batch}x{args.seconds:g}s (log-mel + encoder + greedy decode)",
         "value": round(audio_s / dt, 1), "unit": "audio-sec/wall-sec", "n_gpus": n_ranks, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if args.gemm == "f32" else "f32 (GEMMs: 3-term split on fp16 MFMA, fp32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": f"{args.model} (16-layer Conformer, random-init weights), {args.batch} x {args.seconds:g} s "
                                f"16 kHz utterances per GPU, frontend+encoder+{'CTC' if is_ctc else 'RNN-T'} greedy, "
                                "final all-gather of ids", "global_batch": args.batch * n_ranks,
@@ -202,11 +207,16 @@ def main():
         ms = sum(prof[k]["ms"] for k in fam)
         n = sum(prof[k]["launches"] for k in fam)
         ach = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        if args.gemm == "f32":
+            kern, peak, issued = "gam_gemm_f32_kernel (v_mfma_f32_32x32x2_f32; plain + implicit-GEMM conv)", FP32_MFMA_PEAK_TFLOPS, ach
+        else:
+            # every algorithmic FLOP costs three fp16 MFMA FLOPs (hi.hi + hi.lo + lo.hi)
+            kern, peak, issued = "gam_gemm_f16x3_kernel (3x v_mfma_f32_32x32x16_f16 per product; plain + implicit-GEMM conv)", F16_MFMA_PEAK_TFLOPS, 3.0 * ach
         line["roofline"] = {
-            "kernel": "gam_gemm_f32_kernel (v_mfma_f32_32x32x2_f32; plain + implicit-GEMM conv)", "bound": "mfma",
-            "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": None, "launches_per_step": n // max(1, args.steps),
-            "avg_launch_ms": round(ms / max(1, n), 4), "algorithmic_gflop_per_step": round(flop / args.steps / 1e9, 1),
+            "kernel": kern, "bound": "mfma", "achieved": round(issued, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(issued / peak, 4), "traffic": None, "algorithmic_tflops": round(ach, 2),
+            "launches_per_step": n // max(1, args.steps), "avg_launch_ms": round(ms / max(1, n), 4),
+            "algorithmic_gflop_per_step": round(flop / args.steps / 1e9, 1),
             "share_of_step_time": round(ms / args.steps / ms_step, 3),
         }
         line["kernel_classes_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}

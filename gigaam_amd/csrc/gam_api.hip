@@ -20,6 +20,7 @@
 #include "gam_decode.h"
 #include "gam_frontend.h"
 #include "gam_gemm.h"
+#include "gam_gemm16.h"
 #include "gam_norm.h"
 #include "gam_stem.h"
 
@@ -40,6 +41,12 @@ struct DevBuf {
   size_t cap = 0;  // floats
 };
 
+struct W16 {            // split-fp16 planes of one weight matrix (gam_gemm16.h)
+  _Float16* hi = nullptr;
+  _Float16* lo = nullptr;
+  float inv = 1.0f;
+};
+
 struct LayerW {
   float *ln_ff1_w, *ln_ff1_b, *ff1_w1, *ff1_b1, *ff1_w2, *ff1_b2;
   float *ln_att_w, *ln_att_b, *wqk, *bqk, *wv, *bv, *wo, *bo;
@@ -47,6 +54,7 @@ struct LayerW {
   float *ln_conv_w, *ln_conv_b, *pw1_w, *pw1_b, *dw_w, *dw_b, *cn_scale, *cn_shift, *pw2_w, *pw2_b;
   float *ln_ff2_w, *ln_ff2_b, *ff2_w1, *ff2_b1, *ff2_w2, *ff2_b2;
   float *ln_out_w, *ln_out_b;
+  W16 s_ff1_w1, s_ff1_w2, s_wqk, s_wv, s_wo, s_wpos, s_pw1, s_pw2, s_ff2_w1, s_ff2_w2;
 };
 
 struct ProfEvent {
@@ -70,17 +78,20 @@ struct gam_handle {
   int nf = 0, kpad = 0;
   // stem
   float *c1_w = nullptr, *c1_b = nullptr, *c2_w = nullptr, *c2_b = nullptr, *lin_w = nullptr, *lin_b = nullptr;
+  W16 s_c1, s_c2, s_lin, s_dft;
+  int gemm_mode = 1;  // GAM_GEMM_F16X3
   int f1 = 0, f2 = 0;  // conv2d: feature bins after stage 1 / 2
   // layers
   std::vector<LayerW> layers;
   float *rot_cos = nullptr, *rot_sin = nullptr;
+  float* rel_pe = nullptr;  // rel_pos: sinusoid table, row r + (max_len-1) <-> relative position r
   // heads
   float *ctc_w = nullptr, *ctc_b = nullptr;
   float *jn_enc_w = nullptr, *jn_enc_b = nullptr, *jn_pred_t = nullptr, *jn_pred_b = nullptr;
   float *jn_out_w = nullptr, *jn_out_b = nullptr, *lstm_whh_t = nullptr, *lstm_tab = nullptr;
 
   // workspace (grow-only)
-  DevBuf wavp, spec, img, c2, xin, y1, x, y, yr, hbuf, qk, vbuf, ctx, ubuf, zbuf, tok, logits, encp;
+  DevBuf wavp, spec, img, c2, xin, y1, x, y, yr, hbuf, qk, vbuf, ctx, ubuf, zbuf, tok, logits, encp, pbuf;
   int* lens = nullptr;  // 4 * maxB ints: len0, len1, len2, enc_len
   int lens_cap = 0;
 
@@ -128,6 +139,78 @@ int ensure(gam_handle* h, DevBuf& b, size_t floats) {
   return 0;
 }
 
+uint16_t float_to_half_bits(float f) {   // round to nearest even, subnormals kept
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x7f800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));
+  if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);  // rounds to >= 65520 -> inf
+  if (x < 0x38800000u) {                                      // below 2^-14: subnormal half
+    if (x < 0x33000000u) return (uint16_t)sign;               // < 2^-25 -> 0
+    const int e = (int)(x >> 23);
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    const int shift = 126 - e;                                // 14..24
+    const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    m >>= shift;
+    if (rem > half || (rem == half && (m & 1u))) ++m;
+    return (uint16_t)(sign | m);
+  }
+  const uint32_t e = (x >> 23) - 112u;
+  uint32_t m = x & 0x7fffffu;
+  uint32_t h = (e << 10) | (m >> 13);
+  const uint32_t rem = m & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+  return (uint16_t)(sign | h);
+}
+
+float half_to_float(uint16_t x) {
+  const uint32_t sign = (x >> 15) & 1, exp = (x >> 10) & 0x1f, man = x & 0x3ff;
+  uint32_t f;
+  if (exp == 0) {
+    if (man == 0) f = sign << 31;
+    else {
+      int e = -1; uint32_t m = man;
+      do { ++e; m <<= 1; } while (!(m & 0x400));
+      f = (sign << 31) | ((uint32_t)(127 - 15 - e) << 23) | ((m & 0x3ff) << 13);
+    }
+  } else if (exp == 31) f = (sign << 31) | 0x7f800000u | (man << 13);
+  else f = (sign << 31) | ((exp + 127 - 15) << 23) | (man << 13);
+  float r; memcpy(&r, &f, 4); return r;
+}
+
+
+float half_bits_to_float(uint16_t x) { return half_to_float(x); }
+
+// W * 2^shift = hi + lo with hi, lo in fp16; the power-of-two scale puts max|W| near 2^8 so
+// that lo (~2^-11 |W|) stays in the normal fp16 range for all but negligible entries.
+int make_split(gam_handle* h, const std::vector<float>& w, W16& out) {
+  float mx = 0.f;
+  for (float v : w) mx = std::max(mx, fabsf(v));
+  int shift = 0;
+  if (mx > 0.f && std::isfinite(mx)) shift = (int)floorf(log2f(256.0f / mx));
+  shift = std::max(-24, std::min(24, shift));
+  const float sc = ldexpf(1.0f, shift);
+  std::vector<uint16_t> hi(w.size()), lo(w.size());
+  for (size_t i = 0; i < w.size(); ++i) {
+    const float v = w[i] * sc;
+    const uint16_t hb = float_to_half_bits(v);
+    hi[i] = hb;
+    lo[i] = float_to_half_bits(v - half_bits_to_float(hb));
+  }
+  const size_t bytes = std::max<size_t>(w.size(), 8) * 2 + 64;
+  void *dh = nullptr, *dl = nullptr;
+  if (hipMalloc(&dh, bytes) != hipSuccess || hipMalloc(&dl, bytes) != hipSuccess) return -2;
+  h->owned.push_back(dh);
+  h->owned.push_back(dl);
+  if (hipMemcpy(dh, hi.data(), w.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return -2;
+  if (hipMemcpy(dl, lo.data(), w.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return -2;
+  out.hi = (_Float16*)dh;
+  out.lo = (_Float16*)dl;
+  out.inv = ldexpf(1.0f, -shift);
+  return 0;
+}
+
 const HostTensor* find(gam_handle* h, const std::string& key) {
   auto it = h->staged.find(key);
   return it == h->staged.end() ? nullptr : &it->second;
@@ -156,9 +239,16 @@ struct ProfScope {
   }
 };
 
-int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a, int act, int cls = GAM_PF_GEMM) {
+int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls = GAM_PF_GEMM, const W16* w16 = nullptr) {
+  GamGemmArgs a = a_in;
   ProfScope ps(h, s, cls, 2.0 * (double)a.M * (double)a.N * (double)a.K);
-  hipError_t e = gam_launch_gemm(a, act, s);
+  hipError_t e;
+  if (h->gemm_mode == 1 && w16 != nullptr && w16->hi != nullptr) {
+    a.Whi = w16->hi; a.Wlo = w16->lo; a.wscale_inv = w16->inv;
+    e = gam_launch_gemm16(a, act, s);
+  } else {
+    e = gam_launch_gemm(a, act, s);
+  }
   if (e != hipSuccess) return fail(h, -2, "gemm launch (M=%d N=%d K=%d): %s", a.M, a.N, a.K, hipGetErrorString(e));
   return 0;
 }
@@ -197,6 +287,7 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   h->cfg = *cfg;
   h->device = device_id;
   *out = h;
+  if (const char* e = getenv("GAM_GEMM_MODE")) h->gemm_mode = (strcmp(e, "f32") == 0) ? GAM_GEMM_F32 : GAM_GEMM_F16X3;
   const gam_config& c = h->cfg;
   if (c.d_model <= 0 || c.n_heads <= 0 || c.d_model % c.n_heads != 0)
     return fail(h, -1, "bad d_model/n_heads %d/%d", c.d_model, c.n_heads);
@@ -218,27 +309,12 @@ void gam_destroy(gam_handle* h) {
   hipSetDevice(h->device);
   for (void* p : h->owned) hipFree(p);
   DevBuf* bufs[] = {&h->wavp, &h->spec, &h->img, &h->c2, &h->xin, &h->y1, &h->x, &h->y, &h->yr, &h->hbuf,
-                    &h->qk, &h->vbuf, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp};
+                    &h->qk, &h->vbuf, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   if (h->lens) hipFree(h->lens);
   for (auto& e : h->prof_events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   delete h;
-}
-
-static float half_to_float(uint16_t x) {
-  const uint32_t sign = (x >> 15) & 1, exp = (x >> 10) & 0x1f, man = x & 0x3ff;
-  uint32_t f;
-  if (exp == 0) {
-    if (man == 0) f = sign << 31;
-    else {
-      int e = -1; uint32_t m = man;
-      do { ++e; m <<= 1; } while (!(m & 0x400));
-      f = (sign << 31) | ((uint32_t)(127 - 15 - e) << 23) | ((m & 0x3ff) << 13);
-    }
-  } else if (exp == 31) f = (sign << 31) | 0x7f800000u | (man << 13);
-  else f = (sign << 31) | ((exp + 127 - 15) << 23) | (man << 13);
-  float r; memcpy(&r, &f, 4); return r;
 }
 
 int gam_set_weight(gam_handle* h, const char* key, const void* host_ptr, int dtype, const int64_t* shape, int ndim) {
@@ -297,6 +373,7 @@ int gam_finalize(gam_handle* h) {
         basis[(size_t)(nf + k) * h->kpad + i] = (float)(-win[i] * sin(ang));
       }
     UP(h->dft_basis, basis);
+    if (make_split(h, basis, h->s_dft)) return fail(h, -2, "split upload failed");
     std::vector<float> fb;
     if (const HostTensor* f = find(h, "preprocessor.featurizer.0.mel_scale.fb")) {
       if (f->numel() != (int64_t)nf * c.n_mels) return fail(h, -3, "mel fb has %lld elements, expected %d", (long long)f->numel(), nf * c.n_mels);
@@ -342,6 +419,7 @@ int gam_finalize(gam_handle* h) {
       for (int ci = 0; ci < C; ++ci)
         for (int t = 0; t < 9; ++t) r[((size_t)n * 9 + t) * C + ci] = w2->data[((size_t)n * C + ci) * 9 + t];
     UP(h->c2_w, r);
+    if (make_split(h, r, h->s_c2)) return fail(h, -2, "split upload failed");
     UP(h->c2_b, b2->data);
     // columns c*f2+f -> f*C+c (encoder.py:126-127 flattens channel-major)
     std::vector<float> l((size_t)D * C * h->f2);
@@ -350,6 +428,7 @@ int gam_finalize(gam_handle* h) {
       for (int ci = 0; ci < C; ++ci)
         for (int f = 0; f < f2; ++f) l[(size_t)n * C * f2 + (size_t)f * C + ci] = wl->data[(size_t)n * C * f2 + (size_t)ci * f2 + f];
     UP(h->lin_w, l);
+    if (make_split(h, l, h->s_lin)) return fail(h, -2, "split upload failed");
     UP(h->lin_b, bl->data);
   } else {
     const int ks = c.subs_kernel_size;
@@ -366,8 +445,10 @@ int gam_finalize(gam_handle* h) {
       for (int ci = 0; ci < C; ++ci)
         for (int k = 0; k < ks; ++k) r2[((size_t)n * ks + k) * C + ci] = w2->data[((size_t)n * C + ci) * ks + k];
     UP(h->c1_w, r0);
+    if (make_split(h, r0, h->s_c1)) return fail(h, -2, "split upload failed");
     UP(h->c1_b, b0->data);
     UP(h->c2_w, r2);
+    if (make_split(h, r2, h->s_c2)) return fail(h, -2, "split upload failed");
     UP(h->c2_b, b2->data);
   }
 
@@ -393,8 +474,16 @@ int gam_finalize(gam_handle* h) {
     UP(dstb, b_->data);                                   \
   }
     LN_(L.ln_ff1_w, L.ln_ff1_b, "norm_feed_forward1");
-    LIN_(L.ff1_w1, L.ff1_b1, "feed_forward1.linear1", DFF, D);
-    LIN_(L.ff1_w2, L.ff1_b2, "feed_forward1.linear2", D, DFF);
+#define LINS_(dstw, dstb, dsts, name, nout, nin)                                     \
+  {                                                                                  \
+    NEED(w_, p + name + ".weight", (int64_t)(nout) * (nin));                         \
+    NEED(b_, p + name + ".bias", nout);                                              \
+    UP(dstw, w_->data);                                                              \
+    UP(dstb, b_->data);                                                              \
+    if (make_split(h, w_->data, dsts)) return fail(h, -2, "split upload failed");    \
+  }
+    LINS_(L.ff1_w1, L.ff1_b1, L.s_ff1_w1, "feed_forward1.linear1", DFF, D);
+    LINS_(L.ff1_w2, L.ff1_b2, L.s_ff1_w2, "feed_forward1.linear2", D, DFF);
     LN_(L.ln_att_w, L.ln_att_b, "norm_self_att");
     {
       NEED(wq, p + "self_attn.linear_q.weight", (int64_t)D * D);
@@ -406,19 +495,21 @@ int gam_finalize(gam_handle* h) {
       b.insert(b.end(), bk->data.begin(), bk->data.end());
       UP(L.wqk, w);
       UP(L.bqk, b);
+      if (make_split(h, w, L.s_wqk)) return fail(h, -2, "split upload failed");
     }
-    LIN_(L.wv, L.bv, "self_attn.linear_v", D, D);
-    LIN_(L.wo, L.bo, "self_attn.linear_out", D, D);
+    LINS_(L.wv, L.bv, L.s_wv, "self_attn.linear_v", D, D);
+    LINS_(L.wo, L.bo, L.s_wo, "self_attn.linear_out", D, D);
     if (c.self_attention_model == GAM_ATT_REL_POS) {
       NEED(wp, p + "self_attn.linear_pos.weight", (int64_t)D * D);
       NEED(pu, p + "self_attn.pos_bias_u", D);
       NEED(pv, p + "self_attn.pos_bias_v", D);
       UP(L.wpos, wp->data);
+      if (make_split(h, wp->data, L.s_wpos)) return fail(h, -2, "split upload failed");
       UP(L.pos_u, pu->data);
       UP(L.pos_v, pv->data);
     }
     LN_(L.ln_conv_w, L.ln_conv_b, "norm_conv");
-    LIN_(L.pw1_w, L.pw1_b, "conv.pointwise_conv1", 2 * D, D);
+    LINS_(L.pw1_w, L.pw1_b, L.s_pw1, "conv.pointwise_conv1", 2 * D, D);
     LIN_(L.dw_w, L.dw_b, "conv.depthwise_conv", D, ks);
     {
       NEED(g, p + "conv.batch_norm.weight", D);
@@ -439,13 +530,14 @@ int gam_finalize(gam_handle* h) {
         UP(L.cn_shift, be->data);
       }
     }
-    LIN_(L.pw2_w, L.pw2_b, "conv.pointwise_conv2", D, D);
+    LINS_(L.pw2_w, L.pw2_b, L.s_pw2, "conv.pointwise_conv2", D, D);
     LN_(L.ln_ff2_w, L.ln_ff2_b, "norm_feed_forward2");
-    LIN_(L.ff2_w1, L.ff2_b1, "feed_forward2.linear1", DFF, D);
-    LIN_(L.ff2_w2, L.ff2_b2, "feed_forward2.linear2", D, DFF);
+    LINS_(L.ff2_w1, L.ff2_b1, L.s_ff2_w1, "feed_forward2.linear1", DFF, D);
+    LINS_(L.ff2_w2, L.ff2_b2, L.s_ff2_w2, "feed_forward2.linear2", D, DFF);
     LN_(L.ln_out_w, L.ln_out_b, "norm_out");
 #undef LN_
 #undef LIN_
+#undef LINS_
   }
 
   // ---------------- rotary table (encoder.py:342-355; base = pos_emb_max_len) ----------------
@@ -464,7 +556,19 @@ int gam_finalize(gam_handle* h) {
     UP(h->rot_cos, cs);
     UP(h->rot_sin, sn);
   } else {
-    return fail(h, -4, "rel_pos attention is not built yet");
+    // RelPositionalEmbedding.create_pe (encoder.py:312-327): pe(r)[2i] = sin(r * w_i),
+    // pe(r)[2i+1] = cos(r * w_i), w_i = exp(2i * -(ln 10000 / D)); rows ascending in r
+    const int n = c.pos_emb_max_len;
+    std::vector<float> pe((size_t)(2 * n - 1) * D);
+    for (int i = 0; i < D / 2; ++i) {
+      const float w = expf((float)(2 * i) * (float)(-(log(10000.0) / D)));
+      for (int r = -(n - 1); r <= n - 1; ++r) {
+        const float ang = (float)r * w;
+        pe[(size_t)(r + n - 1) * D + 2 * i] = (float)sin((double)ang);
+        pe[(size_t)(r + n - 1) * D + 2 * i + 1] = (float)cos((double)ang);
+      }
+    }
+    UP(h->rel_pe, pe);
   }
 
   h->has_encoder = build_encoder;
@@ -559,7 +663,7 @@ int gam_frontend(gam_handle* h, const float* wav, const int64_t* wav_len, int B,
     HIPCHK(h, hipMemsetAsync(h->wavp.p + (size_t)B * Lp, 0, (h->kpad + 64) * sizeof(float), s));
   }
   GamGemmArgs g = gemm_args(h->wavp.p, hop, h->dft_basis, nullptr, h->spec.p, lds, (int)(B * Tfa), 2 * h->nf, h->kpad);
-  if (int r = gemm(h, s, g, GAM_ACT_NONE, GAM_PF_FRONTEND)) return r;
+  if (int r = gemm(h, s, g, GAM_ACT_NONE, GAM_PF_FRONTEND, &h->s_dft)) return r;
   {
     GamPowMelArgs a;
     a.spec = h->spec.p; a.fb = h->mel_fb; a.feat = feat; a.wav_len = (const long long*)wav_len; a.feat_len = (long long*)feat_len;
@@ -634,9 +738,9 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     GamGemmArgs g = gemm_args(h->img.p, 0, h->c2_w, h->c2_b, h->c2.p, C, N * F2, C, 9 * C);
     g.a_mode = 1; g.conv_fp = FP; g.conv_c = C; g.conv_f2 = F2;
     g.lens = len2; g.rpb = Ta * F2; g.fdiv = F2;
-    if (int r = gemm(h, s, g, GAM_ACT_RELU, GAM_PF_CONV2)) return r;
+    if (int r = gemm(h, s, g, GAM_ACT_RELU, GAM_PF_CONV2, &h->s_c2)) return r;
     GamGemmArgs l = gemm_args(h->c2.p, (long)F2 * C, h->lin_w, h->lin_b, h->x.p, D, N, D, F2 * C);
-    if (int r = gemm(h, s, l, GAM_ACT_NONE)) return r;
+    if (int r = gemm(h, s, l, GAM_ACT_NONE, GAM_PF_GEMM, &h->s_lin)) return r;
   } else {
     const int ks = c.subs_kernel_size, pad = (ks - 1) / 2;
     // stage-1 input rows per utterance: 2*T1a >= T + 2*pad ; stage-1 output = stage-2 input rows: 2*Ta
@@ -654,14 +758,18 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     GamGemmArgs g1 = gemm_args(h->xin.p, 2L * F, h->c1_w, h->c1_b, h->y1.p, C, B * T1a, C, ks * F);
     g1.lens = len1; g1.rpb = T1a; g1.fdiv = 1;
     g1.remap = 1; g1.out_rpb = 2 * Ta; g1.out_shift = pad; g1.rows_valid = std::min(T1a, 2 * Ta - pad);
-    if (int r = gemm(h, s, g1, GAM_ACT_RELU, GAM_PF_CONV2)) return r;
+    if (int r = gemm(h, s, g1, GAM_ACT_RELU, GAM_PF_CONV2, &h->s_c1)) return r;
     GamGemmArgs g2 = gemm_args(h->y1.p, 2L * C, h->c2_w, h->c2_b, h->x.p, D, N, D, ks * C);
     g2.lens = len2; g2.rpb = Ta; g2.fdiv = 1;
-    if (int r = gemm(h, s, g2, GAM_ACT_RELU, GAM_PF_CONV2)) return r;
+    if (int r = gemm(h, s, g2, GAM_ACT_RELU, GAM_PF_CONV2, &h->s_c2)) return r;
   }
 
   // ------------------------------ Conformer layers ------------------------------
   const int nl = n_layers_run < 0 ? c.n_layers : std::min(n_layers_run, c.n_layers);
+  const bool rel = c.self_attention_model == GAM_ATT_REL_POS;
+  if (rel) {
+    if (int r = ensure(h, h->pbuf, (size_t)(2 * Tv - 1) * D)) return r;
+  }
   GamLnArgs ln;
   memset(&ln, 0, sizeof ln);
   ln.rows = N; ln.d = D; ln.ta = Ta; ln.dk = dk; ln.eps = 1e-5f; ln.rcos = h->rot_cos; ln.rsin = h->rot_sin;
@@ -675,25 +783,32 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     // --- FFN 1 (macaron half step) ---
     {
       GamGemmArgs g = gemm_args(h->y.p, D, L.ff1_w1, L.ff1_b1, h->hbuf.p, DFF, N, DFF, D);
-      if (int r = gemm(h, s, g, GAM_ACT_SILU)) return r;
+      if (int r = gemm(h, s, g, GAM_ACT_SILU, GAM_PF_GEMM, &L.s_ff1_w1)) return r;
       GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff1_w2, L.ff1_b2, h->x.p, D, N, D, DFF);
       g2.R = h->x.p; g2.ldr = D; g2.alpha = 0.5f;
-      if (int r = gemm(h, s, g2, GAM_ACT_NONE)) return r;
+      if (int r = gemm(h, s, g2, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_ff1_w2)) return r;
     }
     // --- self attention ---
     {
       GamLnArgs a = ln;
       a.x = h->x.p; a.out1 = h->y.p; a.out2 = h->yr.p; a.w1 = L.ln_att_w; a.b1 = L.ln_att_b;
-      if (int r = layernorm(h, s, a, 1)) return r;
-      GamGemmArgs gq = gemm_args(h->yr.p, D, L.wqk, L.bqk, h->qk.p, 2 * D, N, 2 * D, D);
-      if (int r = gemm(h, s, gq, GAM_ACT_NONE)) return r;
+      if (int r = layernorm(h, s, a, rel ? 0 : 1)) return r;
+      // rotary: q,k project the rotated copy, v the plain one; rel_pos: all three project y
+      GamGemmArgs gq = gemm_args(rel ? h->y.p : h->yr.p, D, L.wqk, L.bqk, h->qk.p, 2 * D, N, 2 * D, D);
+      if (int r = gemm(h, s, gq, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wqk)) return r;
       GamGemmArgs gv = gemm_args(h->y.p, D, L.wv, L.bv, h->vbuf.p, D, N, D, D);
-      if (int r = gemm(h, s, gv, GAM_ACT_NONE)) return r;
+      if (int r = gemm(h, s, gv, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wv)) return r;
+      if (rel) {  // P = linear_pos(pos_emb) for relative positions -(T'-1) .. T'-1 (no bias)
+        const float* pe0 = h->rel_pe + (size_t)(c.pos_emb_max_len - 1 - (Tv - 1)) * D;
+        GamGemmArgs gp = gemm_args(pe0, D, L.wpos, nullptr, h->pbuf.p, D, 2 * Tv - 1, D, D);
+        if (int r = gemm(h, s, gp, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wpos)) return r;
+      }
       GamAttnArgs at;
       at.q = h->qk.p; at.k = h->qk.p + D; at.v = h->vbuf.p; at.ctx = h->ctx.p;
       at.lens = B > 1 ? len2 : nullptr;  // encoder.py:620-624: no mask at batch 1
       at.B = B; at.Ta = Ta; at.Tv = Tv; at.H = H; at.ldq = 2 * D; at.ldv = D; at.ldo = D;
       at.scale = 1.0f / sqrtf((float)dk);
+      at.pbuf = rel ? h->pbuf.p : nullptr; at.pos_u = L.pos_u; at.pos_v = L.pos_v; at.ldp = D;
       {
         ProfScope ps(h, s, GAM_PF_ATTN, 4.0 * (double)B * H * (double)Tv * Tv * dk);
         hipError_t e = gam_launch_attn(at, dk, s);
@@ -701,7 +816,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       }
       GamGemmArgs go = gemm_args(h->ctx.p, D, L.wo, L.bo, h->x.p, D, N, D, D);
       go.R = h->x.p; go.ldr = D;
-      if (int r = gemm(h, s, go, GAM_ACT_NONE)) return r;
+      if (int r = gemm(h, s, go, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wo)) return r;
     }
     // --- convolution module ---
     {
@@ -709,7 +824,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       a.x = h->x.p; a.out1 = h->y.p; a.w1 = L.ln_conv_w; a.b1 = L.ln_conv_b;
       if (int r = layernorm(h, s, a, 0)) return r;
       GamGemmArgs g1 = gemm_args(h->y.p, D, L.pw1_w, L.pw1_b, h->ubuf.p, 2 * D, N, 2 * D, D);
-      if (int r = gemm(h, s, g1, GAM_ACT_NONE)) return r;
+      if (int r = gemm(h, s, g1, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_pw1)) return r;
       GamConvModArgs cm;
       cm.u = h->ubuf.p; cm.z = h->zbuf.p; cm.dw_w = L.dw_w; cm.dw_b = L.dw_b; cm.n_scale = L.cn_scale; cm.n_shift = L.cn_shift;
       cm.lens = len2; cm.B = B; cm.Ta = Ta; cm.Tv = Tv; cm.d = D; cm.ks = c.conv_kernel_size; cm.eps = 1e-5f;
@@ -720,7 +835,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       }
       GamGemmArgs g2 = gemm_args(h->zbuf.p, D, L.pw2_w, L.pw2_b, h->x.p, D, N, D, D);
       g2.R = h->x.p; g2.ldr = D;
-      if (int r = gemm(h, s, g2, GAM_ACT_NONE)) return r;
+      if (int r = gemm(h, s, g2, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_pw2)) return r;
     }
     // --- FFN 2 ---
     {
@@ -728,10 +843,10 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       a.x = h->x.p; a.out1 = h->y.p; a.w1 = L.ln_ff2_w; a.b1 = L.ln_ff2_b;
       if (int r = layernorm(h, s, a, 0)) return r;
       GamGemmArgs g = gemm_args(h->y.p, D, L.ff2_w1, L.ff2_b1, h->hbuf.p, DFF, N, DFF, D);
-      if (int r = gemm(h, s, g, GAM_ACT_SILU)) return r;
+      if (int r = gemm(h, s, g, GAM_ACT_SILU, GAM_PF_GEMM, &L.s_ff2_w1)) return r;
       GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff2_w2, L.ff2_b2, h->x.p, D, N, D, DFF);
       g2.R = h->x.p; g2.ldr = D; g2.alpha = 0.5f;
-      if (int r = gemm(h, s, g2, GAM_ACT_NONE)) return r;
+      if (int r = gemm(h, s, g2, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_ff2_w2)) return r;
     }
     // --- norm_out (+ next layer's norm_feed_forward1) ---
     {
@@ -848,6 +963,14 @@ int gam_op_gemm(gam_handle* h, const float* A, const float* W, const float* bias
   GamGemmArgs g = gemm_args(A, K, W, bias, C, N, M, N, K);
   return gemm(h, (hipStream_t)stream, g, act);
 }
+
+int gam_set_gemm_mode(gam_handle* h, int mode) {
+  if (!h || (mode != GAM_GEMM_F32 && mode != GAM_GEMM_F16X3)) return fail(h, -1, "unknown GEMM mode %d", mode);
+  h->gemm_mode = mode;
+  return 0;
+}
+
+int gam_get_gemm_mode(const gam_handle* h) { return h ? h->gemm_mode : -1; }
 
 int gam_profile_enable(gam_handle* h, int on) {
   if (!h) return -1;

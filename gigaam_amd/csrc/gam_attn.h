@@ -30,11 +30,19 @@ struct GamAttnArgs {
   int B, Ta, Tv, H;
   long ldq, ldv, ldo;
   float scale;
+  // relative-position variant (v1 models, reference encoder.py:191-228):
+  //   scores[i,j] = ((q_i + u).k_j + (q_i + v).P(i - j)) / sqrt(d_k),  P(r) = W_pos.pe(r)
+  const float* pbuf;   // [2*Tv-1, ldp]: row n <-> relative position n - (Tv-1); head h at column h*dk
+  const float* pos_u;  // [H*dk]
+  const float* pos_v;  // [H*dk]
+  long ldp;
 };
 
+template <bool REL>
 __global__ __launch_bounds__(256) void gam_attn_f32_kernel(GamAttnArgs a) {
   __shared__ __attribute__((aligned(16))) float Ks[GAM_ATT_KT * GAM_ATT_KLD];
   __shared__ __attribute__((aligned(16))) float Vt[GAM_ATT_DK * GAM_ATT_VLD];
+  __shared__ float Gs[REL ? 4 * 80 * 17 : 1];   // per wave: (q+v).P for 80 relative positions x 16 queries
   constexpr int DK = GAM_ATT_DK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -46,6 +54,7 @@ __global__ __launch_bounds__(256) void gam_attn_f32_kernel(GamAttnArgs a) {
 
   // Q fragments (B operand of S^T): lane (query li, kk lg) holds d = 16*s + 4*lg + e
   float4 qf[2][3];
+  float4 qvf[2][3];   // REL only: (q + pos_bias_v) * scale
   int qrow[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -56,6 +65,12 @@ __global__ __launch_bounds__(256) void gam_attn_f32_kernel(GamAttnArgs a) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
       float4 t = *reinterpret_cast<const float4*>(qp + 16 * s);
+      if (REL) {
+        const float4 u = *reinterpret_cast<const float4*>(a.pos_u + h * DK + 4 * lg + 16 * s);
+        const float4 v = *reinterpret_cast<const float4*>(a.pos_v + h * DK + 4 * lg + 16 * s);
+        qvf[j][s] = make_float4((t.x + v.x) * a.scale, (t.y + v.y) * a.scale, (t.z + v.z) * a.scale, (t.w + v.w) * a.scale);
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
       t.x *= a.scale; t.y *= a.scale; t.z *= a.scale; t.w *= a.scale;
       qf[j][s] = t;
     }
@@ -105,6 +120,38 @@ __global__ __launch_bounds__(256) void gam_attn_f32_kernel(GamAttnArgs a) {
         st[kb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.z, qf[1][s].z, st[kb][1], 0, 0, 0);
         st[kb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[0][s].w, st[kb][0], 0, 0, 0);
         st[kb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf.w, qf[1][s].w, st[kb][1], 0, 0, 0);
+      }
+    }
+
+    if (REL) {
+      // ---- S^T[key a][query b] += G[b - a + 63][b],  G[m][b] = P(rlo + m) . (q_b + v) ----
+      float* gw = Gs + wave * (80 * 17);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rlo = (qw0 + j * 16) - kt0 - 63 + (a.Tv - 1);   // pbuf row of m = 0
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+          int prow = rlo + mt * 16 + li;
+          prow = prow < 0 ? 0 : (prow > 2 * a.Tv - 2 ? 2 * a.Tv - 2 : prow);
+          const float* pp = a.pbuf + (size_t)prow * a.ldp + h * DK + 4 * lg;
+          f32x4 gacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < 3; ++s) {
+            const float4 pf = *reinterpret_cast<const float4*>(pp + 16 * s);
+            gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.x, qvf[j][s].x, gacc, 0, 0, 0);
+            gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.y, qvf[j][s].y, gacc, 0, 0, 0);
+            gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.z, qvf[j][s].z, gacc, 0, 0, 0);
+            gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(pf.w, qvf[j][s].w, gacc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gw[(mt * 16 + lg * 4 + r) * 17 + li] = gacc[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[kb][j][r] += gw[(li - (kb * 16 + lg * 4 + r) + 63) * 17 + li];
+        __syncthreads();
       }
     }
 
@@ -184,6 +231,7 @@ __global__ __launch_bounds__(256) void gam_attn_f32_kernel(GamAttnArgs a) {
 static inline hipError_t gam_launch_attn(const GamAttnArgs& a, int dk, hipStream_t s) {
   if (dk != GAM_ATT_DK) return hipErrorInvalidValue;
   dim3 grid(gam_cdiv(a.Ta, 128), a.H, a.B);
-  hipLaunchKernelGGL(gam_attn_f32_kernel, grid, dim3(256), 0, s, a);
+  if (a.pbuf != nullptr) hipLaunchKernelGGL(gam_attn_f32_kernel<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gam_attn_f32_kernel<false>, grid, dim3(256), 0, s, a);
   return hipGetLastError();
 }

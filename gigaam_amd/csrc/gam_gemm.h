@@ -50,6 +50,10 @@ struct GamGemmArgs {
   // row remap: out_row = (m / rpb) * out_rpb + (m % rpb) + out_shift; rows with
   // (m % rpb) >= rows_valid are skipped
   int remap, out_rpb, out_shift, rows_valid;
+  // split-fp16 operand planes of W (gam_gemm16.h): W * 2^wshift = Whi + Wlo (+ ~2^-22 |W|)
+  const _Float16* Whi;
+  const _Float16* Wlo;
+  float wscale_inv;     // 2^-wshift, applied to the accumulator in the epilogue
 };
 
 #define GAM_GEMM_BM 128
@@ -57,6 +61,46 @@ struct GamGemmArgs {
 #define GAM_GEMM_BK 32
 #define GAM_GEMM_LD 36
 #define GAM_GEMM_SMEM(NBUF) ((NBUF) * (GAM_GEMM_BM + GAM_GEMM_BN) * GAM_GEMM_LD * 4)
+
+// ---- shared epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5)
+template <int ACT>
+__device__ __forceinline__ void gam_gemm_epilogue(const GamGemmArgs& g, const f32x16& acc00, const f32x16& acc01,
+                                                  const f32x16& acc10, const f32x16& acc11, int m0, int n0, int wm,
+                                                  int wn, int lane, float accscale) {
+  const int lcol = lane & 31;
+  const int lrow4 = 4 * (lane >> 5);
+#pragma unroll
+  for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
+      if (row >= g.M) continue;
+      bool masked = false;
+      long orow = row;
+      if (g.lens != nullptr || g.remap) {
+        const int bb = row / g.rpb, tt = row - bb * g.rpb;
+        if (g.lens != nullptr) masked = (tt / g.fdiv) >= g.lens[bb];
+        if (g.remap) {
+          if (tt >= g.rows_valid) continue;
+          orow = (long)bb * g.out_rpb + tt + g.out_shift;
+        }
+      }
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int col = n0 + wn * 64 + tn * 32 + lcol;
+        if (col >= g.N) continue;
+        float v = (tm == 0 ? (tn == 0 ? acc00[r] : acc01[r]) : (tn == 0 ? acc10[r] : acc11[r])) * accscale;
+        if (g.bias != nullptr) v += g.bias[col];
+        if (ACT == GAM_ACT_SILU) v = gam_silu(v);
+        if (ACT == GAM_ACT_RELU) v = fmaxf(v, 0.0f);
+        if (masked) v = 0.0f;
+        v *= g.alpha;
+        if (g.R != nullptr) v += g.R[orow * g.ldr + col];
+        g.C[orow * g.ldc + col] = v;
+      }
+    }
+  }
+}
 
 template <int ACT, int NBUF>
 __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gam_gemm_f32_kernel(GamGemmArgs g) {
@@ -200,40 +244,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gam_gemm_f32_kernel(Ga
 #undef GAM_LSTORE
 #undef GAM_MFMA
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*(lane>>5) ----
-  const int lcol = lane & 31;
-  const int lrow4 = 4 * (lane >> 5);
-#pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
-      if (row >= g.M) continue;
-      bool masked = false;
-      long orow = row;
-      if (g.lens != nullptr || g.remap) {
-        const int bb = row / g.rpb, tt = row - bb * g.rpb;
-        if (g.lens != nullptr) masked = (tt / g.fdiv) >= g.lens[bb];
-        if (g.remap) {
-          if (tt >= g.rows_valid) continue;
-          orow = (long)bb * g.out_rpb + tt + g.out_shift;
-        }
-      }
-#pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        const int col = n0 + wn * 64 + tn * 32 + lcol;
-        if (col >= g.N) continue;
-        float v = tm == 0 ? (tn == 0 ? acc00[r] : acc01[r]) : (tn == 0 ? acc10[r] : acc11[r]);
-        if (g.bias != nullptr) v += g.bias[col];
-        if (ACT == GAM_ACT_SILU) v = gam_silu(v);
-        if (ACT == GAM_ACT_RELU) v = fmaxf(v, 0.0f);
-        if (masked) v = 0.0f;
-        v *= g.alpha;
-        if (g.R != nullptr) v += g.R[orow * g.ldr + col];
-        g.C[orow * g.ldc + col] = v;
-      }
-    }
-  }
+  gam_gemm_epilogue<ACT>(g, acc00, acc01, acc10, acc11, m0, n0, wm, wn, lane, 1.0f);
 }
 
 template <int ACT, int NBUF>

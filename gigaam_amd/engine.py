@@ -128,6 +128,15 @@ class HipEngine:
         except Exception:
             pass
 
+    def set_gemm_mode(self, mode: str) -> None:
+        """"f32" (exact fp32 MFMA) or "f16x3" (split-fp16 MFMA, fp32-equivalent; default)."""
+        m = {"f32": _lib.GEMM_F32, "f16x3": _lib.GEMM_F16X3}[mode]
+        self._check(self.lib.gam_set_gemm_mode(self._h, m), "gam_set_gemm_mode")
+
+    @property
+    def gemm_mode(self) -> str:
+        return {_lib.GEMM_F32: "f32", _lib.GEMM_F16X3: "f16x3"}[self.lib.gam_get_gemm_mode(self._h)]
+
     def feat_frames(self, n_samples: int) -> int:
         return int(self.lib.gam_feat_frames(self._h, n_samples))
 

@@ -25,7 +25,8 @@
  *     growth (first call at a larger shape) allocates.
  *   - return value 0 = success, negative = error; gam_last_error() has the message.
  *   - one handle per device; a handle is not thread-safe; distinct handles are independent.
- *   - arithmetic is fp32 end to end (the parity target is the reference's fp32 CPU path).
+ *   - storage and accumulation are fp32 end to end (the parity target is the reference's
+ *     fp32 CPU path); see gam_set_gemm_mode for how the dense contractions are evaluated.
  */
 #ifndef GIGAAM_HIP_H
 #define GIGAAM_HIP_H
@@ -108,6 +109,17 @@ int gam_ctc_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len, 
 int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len, int B, int64_t Tp,
                     int max_symbols, int32_t* ids, int32_t* frames, int32_t* counts,
                     float* logits_dump, int32_t* dump_count, int dump_cap, void* stream);
+
+/* Arithmetic of the dense contractions (every other kernel is plain fp32):
+ *   GAM_GEMM_F32   -- v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain.
+ *   GAM_GEMM_F16X3 -- three-term split on v_mfma_f32_32x32x16_f16 with fp32 accumulation
+ *                     (a = a_hi + a_lo, w = w_hi + w_lo; the a_lo.w_lo term, ~2^-22 relative,
+ *                     is dropped): fp32-equivalent accuracy at several times the rate.
+ * Default: GAM_GEMM_F16X3 (environment GAM_GEMM_MODE=f32 selects the other at gam_create).
+ * The CTC / RNN-T head GEMMs and gam_op_gemm always use GAM_GEMM_F32. */
+enum { GAM_GEMM_F32 = 0, GAM_GEMM_F16X3 = 1 };
+int gam_set_gemm_mode(gam_handle* h, int mode);
+int gam_get_gemm_mode(const gam_handle* h);
 
 /* Raw fp32 GEMM entry for kernel-level tests and the roofline bench:
  * C[M,N] = act(A[M,K] . W[N,K]^T + bias) (act: 0 none, 1 SiLU, 2 ReLU); K % 32 == 0. */

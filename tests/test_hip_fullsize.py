@@ -51,6 +51,27 @@ def test_fullsize_shapes_determinism_and_padding_invariance(full_model):
     assert float(((encp - enc[perm]) * vm).abs().max()) < 1e-4
 
 
+def test_fullsize_split_fp16_vs_exact_fp32_gemm(full_model):
+    """The default split-fp16 MFMA path against the exact-fp32 MFMA path on the full
+    16-layer model: same decode, activations within fp32 round-off of each other."""
+    eng, wav, wlen = full_model
+    assert eng.gemm_mode == "f16x3"
+    feat, flen = eng.frontend(wav[:4], wlen[:4])
+    enc, elen = eng.encode(feat, flen)
+    dec = ragged_from_device(*eng.ctc_greedy(enc, elen))
+    eng.set_gemm_mode("f32")
+    try:
+        feat32, _ = eng.frontend(wav[:4], wlen[:4])
+        enc32, elen32 = eng.encode(feat32, flen)
+        dec32 = ragged_from_device(*eng.ctc_greedy(enc32, elen32))
+    finally:
+        eng.set_gemm_mode("f16x3")
+    vm = (torch.arange(enc.shape[2], device=enc.device)[None, :] < elen[:, None])[:, None, :]
+    assert float(((feat - feat32)).abs().max()) < 2e-3
+    assert float(((enc - enc32) * vm).abs().max()) < 2e-4
+    assert dec == dec32
+
+
 def test_fullsize_matches_oracle_on_one_utterance(full_model):
     """One 16-layer, 20 s utterance against the CPU oracle (a few seconds of CPU time)."""
     from gigaam_amd import synth

@@ -10,13 +10,19 @@ from oracle import gigaam_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-SUPPORTED = [c for c in CASES if not c.startswith("v1_")]  # rel_pos attention: see DESIGN.md
+SUPPORTED = list(CASES)
 
 
-def _engine(ck):
+MODES = ["f16x3", "f32"]   # both arithmetic modes of the dense contractions must hold the same bars
+
+
+def _engine(ck, mode="f16x3"):
     from gigaam_amd.engine import HipEngine, build_config
     cfg = ck["cfg"]
-    return HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], cfg.get("head")), ck["state_dict"], torch.device("cuda:0"))
+    eng = HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], cfg.get("head")), ck["state_dict"], torch.device("cuda:0"))
+    eng.set_gemm_mode(mode)
+    assert eng.gemm_mode == mode
+    return eng
 
 
 def test_gemm_kernel_shapes_and_epilogues():
@@ -39,10 +45,11 @@ def test_gemm_kernel_shapes_and_epilogues():
     assert torch.equal(eng.op_gemm(eye, w).cpu(), w.t().contiguous())  # A = I, asymmetric W: exact
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case", SUPPORTED)
-def test_frontend_matches_oracle(case):
+def test_frontend_matches_oracle(case, mode):
     ck, wav, wlen, gold = load_case(case)
-    eng = _engine(ck)
+    eng = _engine(ck, mode)
     feat_o, flen_o = oracle_features(ck, wav, wlen)
     feat, flen = eng.frontend(wav, wlen)
     assert feat.shape == feat_o.shape and flen.dtype == torch.int64 and flen.cpu().tolist() == flen_o.tolist()
@@ -51,10 +58,11 @@ def test_frontend_matches_oracle(case):
     np.testing.assert_allclose(feat.cpu()[:, ::7, ::13].numpy(), gold["feat_probe"], atol=TOL_FEAT)
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case", SUPPORTED)
-def test_encoder_matches_reference_golden(case):
+def test_encoder_matches_reference_golden(case, mode):
     ck, wav, wlen, gold = load_case(case)
-    eng = _engine(ck)
+    eng = _engine(ck, mode)
     feat_o, flen_o = oracle_features(ck, wav, wlen)
     enc, elen = eng.encode(feat_o, flen_o)
     assert elen.dtype == torch.int32 and elen.cpu().tolist() == gold["enc_len"].tolist()
@@ -66,10 +74,11 @@ def test_encoder_matches_reference_golden(case):
     assert float(((tok.cpu() - torch.from_numpy(gold["pre_encode"])) * vm[:, :, None]).abs().max()) < TOL_ENC
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case", [c for c in SUPPORTED if "ctc" in c])
-def test_ctc_bit_exact_ids_and_frames(case):
+def test_ctc_bit_exact_ids_and_frames(case, mode):
     ck, wav, wlen, gold = load_case(case)
-    eng = _engine(ck)
+    eng = _engine(ck, mode)
     ref = split_ragged(gold["ids"], gold["frames"], gold["counts"].tolist())
     enc_ref = torch.from_numpy(gold["encoded"])
     elen_ref = torch.from_numpy(gold["enc_len"])
@@ -84,11 +93,12 @@ def test_ctc_bit_exact_ids_and_frames(case):
     assert ragged_from_device(*eng.ctc_greedy(enc, elen)) == ref
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("case", [c for c in SUPPORTED if "rnnt" in c])
-def test_rnnt_ids_frames_and_logits(case):
+def test_rnnt_ids_frames_and_logits(case, mode):
     ck, wav, wlen, gold = load_case(case)
     cfg, sd = ck["cfg"], ck["state_dict"]
-    eng = _engine(ck)
+    eng = _engine(ck, mode)
     ms = cfg["decoding"]["max_symbols_per_step"]
     ref = split_ragged(gold["ids"], gold["frames"], gold["counts"].tolist())
     enc_ref = torch.from_numpy(gold["encoded"])
