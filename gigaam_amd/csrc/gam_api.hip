@@ -91,7 +91,9 @@ struct gam_handle {
   float *jn_out_w = nullptr, *jn_out_b = nullptr, *lstm_whh_t = nullptr, *lstm_tab = nullptr;
 
   // workspace (grow-only)
-  DevBuf wavp, spec, img, c2, xin, y1, x, y, yr, hbuf, qk, vbuf, ctx, ubuf, zbuf, tok, logits, encp, pbuf;
+  DevBuf wavp, spec, img, c2, xin, y1, x, y, yr, hbuf, qk, vbuf, ctx, ubuf, zbuf, tok, logits, encp, pbuf, aplanes;
+  int presplit = 0;   // GAM_PRESPLIT=1: split A in a pre-pass (experiment)
+  DevBuf op_planes; const float* op_w = nullptr; size_t op_count = 0;   // gam_op_gemm W-plane cache
   int* lens = nullptr;  // 4 * maxB ints: len0, len1, len2, enc_len
   int lens_cap = 0;
 
@@ -245,6 +247,16 @@ int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls
   hipError_t e;
   if (h->gemm_mode == 1 && w16 != nullptr && w16->hi != nullptr) {
     a.Whi = w16->hi; a.Wlo = w16->lo; a.wscale_inv = w16->inv;
+    if (h->presplit && a.Ahi == nullptr && a.a_mode == 0) {
+      const size_t count = ((size_t)(a.M - 1) * (size_t)a.lda + (size_t)a.K + 7) / 8 * 8;
+      if (int r = ensure(h, h->aplanes, count + 64)) return r;
+      _Float16* hi = (_Float16*)h->aplanes.p;
+      _Float16* lo = hi + count + 8;
+      const size_t n4 = count / 4;
+      const int grid = (int)std::min<size_t>((n4 + 255) / 256, 256 * 16);
+      hipLaunchKernelGGL(gam_split_kernel, dim3(grid), dim3(256), 0, s, a.A, hi, lo, n4);
+      a.Ahi = hi; a.Alo = lo;
+    }
     e = gam_launch_gemm16(a, act, s);
   } else {
     e = gam_launch_gemm(a, act, s);
@@ -287,6 +299,7 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   h->cfg = *cfg;
   h->device = device_id;
   *out = h;
+  if (const char* e = getenv("GAM_PRESPLIT")) h->presplit = atoi(e);
   if (const char* e = getenv("GAM_GEMM_MODE")) h->gemm_mode = (strcmp(e, "f32") == 0) ? GAM_GEMM_F32 : GAM_GEMM_F16X3;
   const gam_config& c = h->cfg;
   if (c.d_model <= 0 || c.n_heads <= 0 || c.d_model % c.n_heads != 0)
@@ -298,7 +311,7 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   if (c.subsampling == GAM_SUBS_CONV1D && c.subs_kernel_size != 5) return fail(h, -1, "conv1d stem needs kernel 5");
   if (c.win_length != c.n_fft) return fail(h, -1, "win_length != n_fft unsupported");
   if (c.n_mels > 64 || c.n_mels != c.feat_in) return fail(h, -1, "n_mels %d / feat_in %d unsupported", c.n_mels, c.feat_in);
-  if (c.head_type == GAM_HEAD_RNNT && (c.pred_rnn_layers != 1 || c.pred_hidden > GAM_RNNT_MAXH || c.joint_hidden > GAM_RNNT_MAXH || c.num_classes > GAM_RNNT_MAXV))
+  if (c.head_type == GAM_HEAD_RNNT && (c.pred_rnn_layers != 1 || c.pred_hidden > GAM_RNNT_MAXH || c.joint_hidden > GAM_RNNT_MAXH || c.num_classes > GAM_RNNT_MAXV || c.joint_hidden % 16 != 0 || c.pred_hidden % 16 != 0))
     return fail(h, -1, "RNN-T head shape unsupported");
   if (hipSetDevice(device_id) != hipSuccess) return fail(h, -2, "hipSetDevice(%d) failed", device_id);
   return 0;
@@ -309,7 +322,7 @@ void gam_destroy(gam_handle* h) {
   hipSetDevice(h->device);
   for (void* p : h->owned) hipFree(p);
   DevBuf* bufs[] = {&h->wavp, &h->spec, &h->img, &h->c2, &h->xin, &h->y1, &h->x, &h->y, &h->yr, &h->hbuf,
-                    &h->qk, &h->vbuf, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf};
+                    &h->qk, &h->vbuf, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   if (h->lens) hipFree(h->lens);
@@ -951,7 +964,17 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
   a.dump = logits_dump; a.dump_count = dump_count; a.B = B; a.Tp = (int)Tp; a.V = c.num_classes; a.H = c.pred_hidden; a.JH = JH;
   a.max_symbols = max_symbols; a.cap = (int)Tp * max_symbols; a.dump_cap = logits_dump ? dump_cap : 0;
   ProfScope ps(h, s, GAM_PF_DECODE, 0.0);
-  hipLaunchKernelGGL(gam_rnnt_greedy_kernel, dim3(B), dim3(256), 0, s, a);
+  a.wout_in_lds = gam_rnnt_smem(a.H, a.JH, a.V, 1) <= 96 * 1024 ? 1 : 0;
+  const size_t sm = gam_rnnt_smem(a.H, a.JH, a.V, a.wout_in_lds);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gam_rnnt_greedy_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gam_rnnt_greedy_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  if (sm > 160 * 1024) return fail(h, -1, "RNN-T head too large for the greedy kernel's LDS window");
+  if (4 * a.H <= 256 * 5) hipLaunchKernelGGL(gam_rnnt_greedy_kernel<5>, dim3(B), dim3(256), sm, s, a);
+  else hipLaunchKernelGGL(gam_rnnt_greedy_kernel<8>, dim3(B), dim3(256), sm, s, a);
   HIPCHK(h, hipGetLastError());
   return 0;
 }
@@ -961,7 +984,20 @@ int gam_op_gemm(gam_handle* h, const float* A, const float* W, const float* bias
   if (!h) return -1;
   HIPCHK(h, hipSetDevice(h->device));
   GamGemmArgs g = gemm_args(A, K, W, bias, C, N, M, N, K);
-  return gemm(h, (hipStream_t)stream, g, act);
+  if (h->gemm_mode != GAM_GEMM_F16X3) return gemm(h, (hipStream_t)stream, g, act);
+  // split-fp16 mode: W planes are built on the device (unit scale) and cached per W pointer
+  hipStream_t s = (hipStream_t)stream;
+  const size_t count = ((size_t)N * K + 7) / 8 * 8;
+  if (h->op_w != W || h->op_count != count) {
+    if (int r = ensure(h, h->op_planes, count + 64)) return r;
+    _Float16* hi = (_Float16*)h->op_planes.p;
+    hipLaunchKernelGGL(gam_split_kernel, dim3((int)std::min<size_t>((count / 4 + 255) / 256, 4096)), dim3(256), 0, s, W, hi,
+                       hi + count + 8, count / 4);
+    h->op_w = W; h->op_count = count;
+  }
+  W16 w16;
+  w16.hi = (_Float16*)h->op_planes.p; w16.lo = w16.hi + count + 8; w16.inv = 1.0f;
+  return gemm(h, s, g, act, GAM_PF_GEMM, &w16);
 }
 
 int gam_set_gemm_mode(gam_handle* h, int mode) {

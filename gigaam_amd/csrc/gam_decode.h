@@ -81,12 +81,20 @@ __global__ __launch_bounds__(256) void gam_ctc_greedy_kernel(const float* logits
 }
 
 // ------------------------------------------------------------------ RNN-T greedy
-// One persistent workgroup per utterance runs the whole frame/symbol loop on device.
-// The reference re-runs predict(last_label, state) on every step although its inputs
-// only change after a non-blank emission (decoding.py:156-160,175-178); here the
-// candidate (g, h', c') and W_pred.g are computed once per commit and reused.  The
-// encoder half of the joint (W_enc.f_t + b) is hoisted to one GEMM over all frames, and
-// W_ih.embed[v] + b_ih + b_hh is a [V, 4H] table built at finalize.
+// One persistent workgroup per utterance runs the whole frame/symbol loop on device, no
+// host syncs (reference: >= 3 per step, decoding.py:165,171,173).
+//
+//  * The reference re-runs predict(last_label, state) on every step although its inputs
+//    only change after a non-blank emission (decoding.py:156-160,175-178): here the
+//    candidate (g, h', c') and W_pred.g are computed once per commit and reused.
+//  * The encoder half of the joint (W_enc.f_t + b) is hoisted to one GEMM over all frames;
+//    W_ih.embed[v] + b_ih + b_hh is a [V+1, 4H] table built at finalize.
+//  * Between two emissions the predictor term is constant, so the joint of the next
+//    WIN = 16 frames is evaluated at once as a [16 x JH] x [JH x V] product on the matrix
+//    cores (v_mfma_f32_16x16x4_f32) and scanned for the first non-blank frame: every frame
+//    before it is a confirmed blank step, everything after it is discarded and re-evaluated
+//    with the new predictor state.  Same arithmetic per (frame, state) as the sequential
+//    loop, ~T/16 + #tokens steps instead of T + #tokens.
 struct GamRnntArgs {
   const float* encp;     // [B*Tp, JH]  W_enc.f + b_enc
   const int* enc_len;    // [B]
@@ -99,110 +107,174 @@ struct GamRnntArgs {
   int* ids; int* frames; int* counts;   // [B, cap], [B, cap], [B]
   float* dump; int* dump_count;         // optional [B, dump_cap, V] log-probs of every joint call
   int B, Tp, V, H, JH, max_symbols, cap, dump_cap;
+  int wout_in_lds;       // set by the launcher: W_out (V x JH fp32) is cached in LDS
 };
 
 #define GAM_RNNT_MAXH 512
 #define GAM_RNNT_RPT 8   // gate rows per thread: 4*H <= 2048
 #define GAM_RNNT_MAXV 2048
+#define GAM_RNNT_WIN 16
 
+static inline size_t gam_rnnt_smem(int H, int JH, int V, int wout_in_lds) {
+  const int vp = (V + 15) / 16 * 16;
+  size_t f = (size_t)8 * H + 2 * JH + (size_t)GAM_RNNT_WIN * (JH + 4) + (size_t)GAM_RNNT_WIN * (vp + 1) + 64 + 16;
+  if (wout_in_lds) f += (size_t)V * (JH + 4);
+  return sizeof(float) * f;
+}
+
+template <int NR>   // gate rows per thread: 4*H <= 256*NR
 __global__ __launch_bounds__(256) void gam_rnnt_greedy_kernel(GamRnntArgs a) {
-  __shared__ float h_s[GAM_RNNT_MAXH], c_s[GAM_RNNT_MAXH];      // committed state
-  __shared__ float hn_s[GAM_RNNT_MAXH], cn_s[GAM_RNNT_MAXH];    // candidate state (= g)
-  __shared__ float gates[4 * GAM_RNNT_MAXH];
-  __shared__ float pp[GAM_RNNT_MAXH];                           // W_pred.g + b_pred
-  __shared__ float zj[GAM_RNNT_MAXH];                           // relu(enc + pred)
-  __shared__ float lg[GAM_RNNT_MAXV];
-  __shared__ float red_v[4];
-  __shared__ int red_i[4];
-  __shared__ float lse_s;
-  __shared__ int k_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.x;
+  extern __shared__ __attribute__((aligned(16))) float gam_smem_rnnt[];
   const int H = a.H, JH = a.JH, V = a.V, blank = a.V - 1;
+  const int VP = (V + 15) / 16 * 16, ZLD = JH + 4, LLD = VP + 1;
+  float* h_s = gam_smem_rnnt;            // committed state
+  float* c_s = h_s + H;
+  float* hn_s = c_s + H;                 // candidate state (= g)
+  float* cn_s = hn_s + H;
+  float* gates = cn_s + H;               // [4H]
+  float* pp = gates + 4 * H;             // W_pred.g + b_pred  [JH]
+  float* zw = pp + 2 * JH;               // [WIN][ZLD]  relu(enc + pred)   (16-byte aligned: 8H + 2JH floats)
+  float* lgw = zw + GAM_RNNT_WIN * ZLD;  // [WIN][LLD]  logits
+  int* lab_s = reinterpret_cast<int*>(lgw + GAM_RNNT_WIN * LLD);   // [WIN]
+  float* mx_s = reinterpret_cast<float*>(lab_s + GAM_RNNT_WIN);    // [WIN]
+  float* lse_s = mx_s + GAM_RNNT_WIN;                              // [WIN]
+  const int WLD = JH + 4;
+  float* wout_l = a.wout_in_lds ? lse_s + GAM_RNNT_WIN + 12 : nullptr;   // [V][WLD], 16-byte aligned
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg4 = lane >> 4;
+  const int b = blockIdx.x;
   int len = a.enc_len[b];
   len = len < 0 ? 0 : (len > a.Tp ? a.Tp : len);
 
   for (int i = tid; i < H; i += 256) { h_s[i] = 0.f; c_s[i] = 0.f; }
+  if (wout_l != nullptr)
+    for (int i = tid; i < V * JH; i += 256) wout_l[(i / JH) * WLD + (i % JH)] = a.wout[i];
   __syncthreads();
 
   int label = V;       // gate_tab row V: zero embedding (predict(None, None), decoder.py:97-100)
   int n_out = 0, n_dump = 0;
+  int t = 0, sym = 0;  // current frame, symbols already emitted on it
   bool need_pred = true;
 
-  for (int t = 0; t < len; ++t) {
-    const float* ef = a.encp + ((size_t)b * a.Tp + t) * JH;
-    for (int sym = 0; sym < a.max_symbols; ++sym) {
-      if (need_pred) {
-        // ---- LSTM cell: gates = tab[label] + W_hh.h  (gate order i,f,g,o) ----
-        // thread = gate row(s), W_hh^T rows are contiguous over the gate index, so a wave
-        // reads 256 B per k; up to GAM_RNNT_RPT rows per thread give independent loads.
-        {
-          float acc[GAM_RNNT_RPT];
+  while (t < len) {
+    if (need_pred) {
+      // ---- LSTM cell: gates = tab[label] + W_hh.h  (gate order i,f,g,o); thread = gate row(s),
+      //      W_hh^T rows are contiguous over the gate index (coalesced), 8 k in flight ----
+      {
+        // 16 k x NR rows of W_hh^T in flight per thread: the step is L2-latency-bound, so the
+        // number of independent loads per wait is what sets its duration.  Every load is
+        // unconditional (row index clamped): a per-element "load or 0" select makes hipcc
+        // branch around each load and wait for it (cdna_hip_programming.md §5 trap c).
+        float acc[NR];
+        int roff[NR];
 #pragma unroll
-          for (int j = 0; j < GAM_RNNT_RPT; ++j) {
-            const int r = tid + 256 * j;
-            acc[j] = r < 4 * H ? a.gate_tab[(size_t)label * 4 * H + r] : 0.f;
-          }
-          for (int k = 0; k < H; ++k) {
-            const float hk = h_s[k];
-            const float* wt = a.whh_t + (size_t)k * 4 * H + tid;
+        for (int j = 0; j < NR; ++j) {
+          roff[j] = tid + 256 * j < 4 * H ? tid + 256 * j : 4 * H - 1;
+          acc[j] = a.gate_tab[(size_t)label * 4 * H + roff[j]];
+        }
+        for (int k0 = 0; k0 < H; k0 += 16) {          // H % 16 == 0 (checked at gam_create)
+          float w[16][NR];
 #pragma unroll
-            for (int j = 0; j < GAM_RNNT_RPT; ++j)
-              if (tid + 256 * j < 4 * H) acc[j] = fmaf(wt[256 * j], hk, acc[j]);
-          }
+          for (int kk = 0; kk < 16; ++kk)
 #pragma unroll
-          for (int j = 0; j < GAM_RNNT_RPT; ++j)
-            if (tid + 256 * j < 4 * H) gates[tid + 256 * j] = acc[j];
-        }
-        __syncthreads();
-        for (int i = tid; i < H; i += 256) {
-          const float ig = gam_sigmoid(gates[i]), fg = gam_sigmoid(gates[H + i]);
-          const float gg = tanhf(gates[2 * H + i]), og = gam_sigmoid(gates[3 * H + i]);
-          const float cn = fg * c_s[i] + ig * gg;
-          cn_s[i] = cn;
-          hn_s[i] = og * tanhf(cn);
-        }
-        __syncthreads();
-        {
-          float acc0 = tid < JH ? a.bpred[tid] : 0.f, acc1 = tid + 256 < JH ? a.bpred[tid + 256] : 0.f;
-#pragma unroll 4
-          for (int k = 0; k < H; ++k) {
-            const float gk = hn_s[k];
-            const float* wt = a.wpred_t + (size_t)k * JH + tid;
-            if (tid < JH) acc0 = fmaf(wt[0], gk, acc0);
-            if (tid + 256 < JH) acc1 = fmaf(wt[256], gk, acc1);
+            for (int j = 0; j < NR; ++j) w[kk][j] = a.whh_t[(size_t)(k0 + kk) * 4 * H + roff[j]];
+#pragma unroll
+          for (int kk = 0; kk < 16; ++kk) {
+            const float hk = h_s[k0 + kk];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) acc[j] = fmaf(w[kk][j], hk, acc[j]);
           }
-          if (tid < JH) pp[tid] = acc0;
-          if (tid + 256 < JH) pp[tid + 256] = acc1;
         }
-        need_pred = false;
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+          if (tid + 256 * j < 4 * H) gates[tid + 256 * j] = acc[j];
       }
-      // ---- joint: logits = W_out . relu(enc_t + pred) + b_out ----
-      for (int i = tid; i < JH; i += 256) zj[i] = fmaxf(ef[i] + pp[i], 0.f);
+      __syncthreads();
+      for (int i = tid; i < H; i += 256) {
+        const float ig = gam_sigmoid_exact(gates[i]), fg = gam_sigmoid_exact(gates[H + i]);
+        const float gg = tanhf(gates[2 * H + i]), og = gam_sigmoid_exact(gates[3 * H + i]);
+        const float cn = fg * c_s[i] + ig * gg;
+        cn_s[i] = cn;
+        hn_s[i] = og * tanhf(cn);
+      }
       __syncthreads();
       {
-        // one wave per class: lanes stride over the joint dimension (coalesced 256 B
-        // reads of W_out rows), z is hoisted into registers, wave-reduce per class.
-        float zr[GAM_RNNT_MAXH / 64];
+        float acc0 = tid < JH ? a.bpred[tid] : 0.f, acc1 = tid + 256 < JH ? a.bpred[tid + 256] : 0.f;
+        const int r0 = tid < JH ? tid : JH - 1, r1 = tid + 256 < JH ? tid + 256 : JH - 1;
+        for (int k0 = 0; k0 < H; k0 += 32) {
+          float w0[32], w1[32];
 #pragma unroll
-        for (int j = 0; j < GAM_RNNT_MAXH / 64; ++j) zr[j] = lane + 64 * j < JH ? zj[lane + 64 * j] : 0.f;
-        for (int v = wave; v < V; v += 4) {
-          const float* wr = a.wout + (size_t)v * JH + lane;
-          float acc = 0.f;
+          for (int kk = 0; kk < 32; ++kk) {
+            const int k = k0 + kk < H ? k0 + kk : H - 1;
+            w0[kk] = a.wpred_t[(size_t)k * JH + r0];
+            w1[kk] = a.wpred_t[(size_t)k * JH + r1];
+          }
 #pragma unroll
-          for (int j = 0; j < GAM_RNNT_MAXH / 64; ++j)
-            if (lane + 64 * j < JH) acc = fmaf(wr[64 * j], zr[j], acc);
-          acc = gam_wave_sum(acc);
-          if (lane == 0) lg[v] = acc + a.bout[v];
+          for (int kk = 0; kk < 32; ++kk) {
+            const float gk = k0 + kk < H ? hn_s[k0 + kk] : 0.f;
+            acc0 = fmaf(w0[kk], gk, acc0);
+            acc1 = fmaf(w1[kk], gk, acc1);
+          }
+        }
+        if (tid < JH) pp[tid] = acc0;
+        if (tid + 256 < JH) pp[tid + 256] = acc1;
+      }
+      need_pred = false;
+      __syncthreads();
+    }
+
+    // ---- joint of frames t .. t+W-1 with the current predictor state ----
+    const int W = len - t < GAM_RNNT_WIN ? len - t : GAM_RNNT_WIN;
+    for (int idx = tid; idx < GAM_RNNT_WIN * JH; idx += 256) {
+      const int f = idx / JH, k = idx - f * JH;
+      const int tt = t + (f < W ? f : W - 1);
+      zw[f * ZLD + k] = fmaxf(a.encp[((size_t)b * a.Tp + tt) * JH + k] + pp[k], 0.f);
+    }
+    __syncthreads();
+    // logits[f][v] = bout[v] + sum_k z[f][k] * wout[v][k]: one 16x16 MFMA tile per 16 classes
+    for (int nt = wave; nt * 16 < VP; nt += 4) {
+      int v = nt * 16 + li;
+      const int vc = v < V ? v : V - 1;
+      // W_out rows: from the LDS copy when the whole matrix fits (char vocabularies), else L2
+      const float* wr = (wout_l != nullptr ? wout_l + (size_t)vc * WLD : a.wout + (size_t)vc * JH) + 4 * lg4;
+      const float* zr = zw + li * ZLD + 4 * lg4;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int k0 = 0; k0 + 64 <= JH; k0 += 64) {      // 4 loads in flight per step
+        float4 wf[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const float4*>(wr + k0 + 16 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float4 zf = *reinterpret_cast<const float4*>(zr + k0 + 16 * u);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.x, wf[u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf[u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf[u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf[u].w, acc, 0, 0, 0);
         }
       }
-      __syncthreads();
-      // ---- argmax (first max) ----
+      for (int k0 = JH / 64 * 64; k0 + 16 <= JH; k0 += 16) {
+        const float4 zf = *reinterpret_cast<const float4*>(zr + k0);
+        const float4 wf = *reinterpret_cast<const float4*>(wr + k0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.x, wf.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf.w, acc, 0, 0, 0);
+      }
+      // C/D: col = lane&15 = class, row = 4*(lane>>4) + r = frame
+      if (v < V) {
+        const float bo = a.bout[v];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lgw[(4 * lg4 + r) * LLD + v] = acc[r] + bo;
+      }
+    }
+    __syncthreads();
+    // per-frame argmax (first max) + log-sum-exp: wave w takes frames w, w+4, ...
+    for (int f = wave; f < W; f += 4) {
+      const float* lr = lgw + f * LLD;
       float best = -INFINITY;
       int bi = 0x7fffffff;
-      for (int v = tid; v < V; v += 256) {
-        const float x = lg[v];
+      for (int v = lane; v < V; v += 64) {
+        const float x = lr[v];
         if (x > best || (x == best && v < bi)) { best = x; bi = v; }
       }
 #pragma unroll
@@ -211,44 +283,49 @@ __global__ __launch_bounds__(256) void gam_rnnt_greedy_kernel(GamRnntArgs a) {
         const int oi = __shfl_xor(bi, o, 64);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
       }
-      if (lane == 0) { red_v[wave] = best; red_i[wave] = bi; }
-      __syncthreads();
-      if (tid == 0) {
-        float bb = red_v[0]; int ii = red_i[0];
-        for (int w = 1; w < 4; ++w)
-          if (red_v[w] > bb || (red_v[w] == bb && red_i[w] < ii)) { bb = red_v[w]; ii = red_i[w]; }
-        k_s = ii;
-        red_v[0] = bb;
+      float se = 0.f;
+      if (a.dump != nullptr) {
+        for (int v = lane; v < V; v += 64) se += expf(lr[v] - best);
+        se = gam_wave_sum(se);
       }
-      __syncthreads();
-      const int k = k_s;
-      if (a.dump != nullptr && n_dump < a.dump_cap) {   // log_softmax of this joint call
-        const float mx = red_v[0];
-        float s = 0.f;
-        for (int v = tid; v < V; v += 256) s += expf(lg[v] - mx);
-        s = gam_wave_sum(s);
-        __syncthreads();
-        if (lane == 0) red_v[wave] = s;
-        __syncthreads();
-        if (tid == 0) lse_s = mx + logf(red_v[0] + red_v[1] + red_v[2] + red_v[3]);
-        __syncthreads();
-        float* dp = a.dump + ((size_t)b * a.dump_cap + n_dump) * V;
-        for (int v = tid; v < V; v += 256) dp[v] = lg[v] - lse_s;
+      if (lane == 0) { lab_s[f] = bi; mx_s[f] = best; lse_s[f] = best + logf(se); }
+    }
+    __syncthreads();
+    // first non-blank frame of the window (uniform scan, W <= 16)
+    int fstar = W;
+    for (int f = 0; f < W; ++f)
+      if (lab_s[f] != blank) { fstar = f; break; }
+    const int n_eval = fstar < W ? fstar + 1 : W;   // joint evaluations the sequential loop performs
+    if (a.dump != nullptr) {
+      for (int f = 0; f < n_eval; ++f) {
+        if (n_dump + f < a.dump_cap) {
+          float* dp = a.dump + ((size_t)b * a.dump_cap + n_dump + f) * V;
+          const float lse = lse_s[f];
+          for (int v = tid; v < V; v += 256) dp[v] = lgw[f * LLD + v] - lse;
+        }
       }
-      ++n_dump;
-      __syncthreads();
-      if (k == blank) break;
-      // ---- emit + commit (decoding.py:175-178) ----
+    }
+    n_dump += n_eval;
+    if (fstar == W) {            // W blank frames
+      t += W;
+      sym = 0;
+    } else {                     // emission at frame t + fstar (decoding.py:175-178)
+      const int k = lab_s[fstar];
+      const int te = t + fstar;
+      if (fstar > 0) sym = 0;
       if (tid == 0 && n_out < a.cap) {
         a.ids[(size_t)b * a.cap + n_out] = k;
-        a.frames[(size_t)b * a.cap + n_out] = t;
+        a.frames[(size_t)b * a.cap + n_out] = te;
       }
       ++n_out;
+      ++sym;
       label = k;
       for (int i = tid; i < H; i += 256) { h_s[i] = hn_s[i]; c_s[i] = cn_s[i]; }
       need_pred = true;
-      __syncthreads();
+      if (sym >= a.max_symbols) { t = te + 1; sym = 0; }   // frame advances regardless (decoding.py:189-205)
+      else t = te;
     }
+    __syncthreads();
   }
   if (tid == 0) {
     a.counts[b] = n_out < a.cap ? n_out : a.cap;

@@ -53,6 +53,11 @@ struct GamGemmArgs {
   // split-fp16 operand planes of W (gam_gemm16.h): W * 2^wshift = Whi + Wlo (+ ~2^-22 |W|)
   const _Float16* Whi;
   const _Float16* Wlo;
+  // optional split planes of A (same element indexing as the fp32 A, lda in elements):
+  // produced by gam_split_kernel or directly by the producing kernel
+  const _Float16* Ahi;
+  const _Float16* Alo;
+  int ntiles;           // set by the launcher (persistent tile loop of gam_gemm16.h)
   float wscale_inv;     // 2^-wshift, applied to the accumulator in the epilogue
 };
 

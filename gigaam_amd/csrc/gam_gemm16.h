@@ -39,7 +39,7 @@ __device__ __forceinline__ void gam_split4(const f32x4 v, gam_half4& hi, gam_hal
                    (_Float16)(v.w - (float)h3)};
 }
 
-template <int ACT, int BK>
+template <int ACT, int BK, bool AP>
 __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gam_gemm_f16x3_kernel(GamGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) _Float16 gam_smem16[];
   using Cfg = GamGemm16Cfg<BK>;
@@ -54,10 +54,13 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gam_gemm_f16x3_kernel(G
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
+  // Persistent over output tiles: workgroup b takes tiles b, b + gridDim.x, ... (gridDim.x
+  // is a multiple of 8 whenever it is smaller than the tile count, so a workgroup stays on
+  // its XCD's tile range).  A finished tile's stores drain behind the next tile's loads.
   const int nbn = (g.N + BN - 1) / BN;
-  const int total = gridDim.x;
-  const int bid = blockIdx.x;
+  const int total = g.ntiles;
   const int q8 = total >> 3, r8 = total & 7;
+  for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
   const int xcd = bid & 7;
   const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int m0 = (lid / nbn) * BM;
@@ -65,13 +68,15 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gam_gemm_f16x3_kernel(G
 
   // ---- A staging: float4 index f = tid + 256*i over [128 rows][BK/4];  W staging: 16 B chunk
   //      c = tid + 256*i over [128 rows][BK/8] per plane
-  constexpr int AF = Cfg::A_F4, WC = Cfg::W_CH, F4R = BK / 4, CHR = BK / 8;
-  const float* pa[AF];
+  // AP = true: A arrives as fp16 planes (16-byte chunks, like W); AP = false: fp32, split here
+  constexpr int AF = AP ? Cfg::W_CH : Cfg::A_F4, WC = Cfg::W_CH, F4R = AP ? BK / 8 : BK / 4, CHR = BK / 8;
+  constexpr int AEL = AP ? 8 : 4;   // elements per A staging item
+  size_t a_off[AF];
   int a_lds[AF];
 #pragma unroll
   for (int i = 0; i < AF; ++i) {
     const int f = tid + 256 * i;
-    const int row = f / F4R, c4 = (f % F4R) * 4;
+    const int row = f / F4R, c4 = (f % F4R) * AEL;
     int m = m0 + row;
     m = m < g.M ? m : g.M - 1;
     size_t off;
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gam_gemm_f16x3_kernel(G
       const int fr = m / g.conv_f2, ff = m - fr * g.conv_f2;
       off = ((size_t)fr * 2 * g.conv_fp + 2 * ff) * (size_t)g.conv_c;
     }
-    pa[i] = g.A + off + c4;
+    a_off[i] = off + c4;
     a_lds[i] = row * LD + c4;
   }
   size_t w_off[WC];
@@ -100,7 +105,8 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gam_gemm_f16x3_kernel(G
   for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
 
   const int nk = g.K / BK;
-  f32x4 va[AF];
+  f32x4 va[AP ? 1 : AF];
+  gam_u32x4 vah[AP ? AF : 1], val[AP ? AF : 1];
   gam_u32x4 vh[WC], vl[WC];
 
   auto gload = [&](int kt) {
@@ -111,8 +117,16 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gam_gemm_f16x3_kernel(G
       const int kh = tap / 3, kw = tap - kh * 3;
       ka = ((size_t)kh * g.conv_fp + kw) * (size_t)g.conv_c + c0;
     }
+    if constexpr (AP) {
 #pragma unroll
-    for (int i = 0; i < AF; ++i) va[i] = *reinterpret_cast<const f32x4*>(pa[i] + ka);
+      for (int i = 0; i < AF; ++i) {
+        vah[i] = *reinterpret_cast<const gam_u32x4*>(g.Ahi + a_off[i] + ka);
+        val[i] = *reinterpret_cast<const gam_u32x4*>(g.Alo + a_off[i] + ka);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AF; ++i) va[i] = *reinterpret_cast<const f32x4*>(g.A + a_off[i] + ka);
+    }
 #pragma unroll
     for (int i = 0; i < WC; ++i) {
       vh[i] = *reinterpret_cast<const gam_u32x4*>(g.Whi + w_off[i] + k0);
@@ -120,12 +134,20 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gam_gemm_f16x3_kernel(G
     }
   };
   auto lstore = [&]() {
+    if constexpr (AP) {
 #pragma unroll
-    for (int i = 0; i < AF; ++i) {
-      gam_half4 hi, lo;
-      gam_split4(va[i], hi, lo);
-      *reinterpret_cast<gam_half4*>(Ahi + a_lds[i]) = hi;
-      *reinterpret_cast<gam_half4*>(Alo + a_lds[i]) = lo;
+      for (int i = 0; i < AF; ++i) {
+        *reinterpret_cast<gam_u32x4*>(Ahi + a_lds[i]) = vah[i];
+        *reinterpret_cast<gam_u32x4*>(Alo + a_lds[i]) = val[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < AF; ++i) {
+        gam_half4 hi, lo;
+        gam_split4(va[i], hi, lo);
+        *reinterpret_cast<gam_half4*>(Ahi + a_lds[i]) = hi;
+        *reinterpret_cast<gam_half4*>(Alo + a_lds[i]) = lo;
+      }
     }
 #pragma unroll
     for (int i = 0; i < WC; ++i) {
@@ -160,17 +182,31 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gam_gemm_f16x3_kernel(G
   }
 #undef GAM_MF16
   gam_gemm_epilogue<ACT>(g, acc00, acc01, acc10, acc11, m0, n0, wm, wn, lane, g.wscale_inv);
+  }  // tile loop
 }
 
-template <int ACT, int BK>
+template <int ACT, int BK, bool AP>
 static inline void gam_launch_gemm16_t(const GamGemmArgs& a, int grid, hipStream_t stream) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gam_gemm_f16x3_kernel<ACT, BK>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gam_gemm_f16x3_kernel<ACT, BK, AP>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, GamGemm16Cfg<BK>::SMEM);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gam_gemm_f16x3_kernel<ACT, BK>), dim3(grid), dim3(256), GamGemm16Cfg<BK>::SMEM, stream, a);
+  hipLaunchKernelGGL((gam_gemm_f16x3_kernel<ACT, BK, AP>), dim3(grid), dim3(256), GamGemm16Cfg<BK>::SMEM, stream, a);
+}
+
+// fp32 -> (hi, lo) fp16 planes over a flat range (elementwise, HBM-bound: 4 B in, 4 B out)
+__global__ __launch_bounds__(256) void gam_split_kernel(const float* __restrict__ x, _Float16* __restrict__ hi,
+                                                        _Float16* __restrict__ lo, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    gam_half4 h, l;
+    gam_split4(v, h, l);
+    reinterpret_cast<gam_half4*>(hi)[i] = h;
+    reinterpret_cast<gam_half4*>(lo)[i] = l;
+  }
 }
 
 static inline int gam_gemm16_bk() {
@@ -182,15 +218,30 @@ static inline int gam_gemm16_bk() {
   return v;
 }
 
-static inline hipError_t gam_launch_gemm16(const GamGemmArgs& a, int act, hipStream_t stream) {
+static inline int gam_gemm16_persist() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("GAM_PERSIST");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+static inline hipError_t gam_launch_gemm16(const GamGemmArgs& a_in, int act, hipStream_t stream) {
+  GamGemmArgs a = a_in;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K <= 0 || a.Whi == nullptr || a.Wlo == nullptr) return hipErrorInvalidValue;
-  const int grid = gam_cdiv(a.M, 128) * gam_cdiv(a.N, 128);
+  a.ntiles = gam_cdiv(a.M, 128) * gam_cdiv(a.N, 128);
+  // 256 CUs x 3 resident workgroups
+  const int grid = gam_gemm16_persist() ? (a.ntiles < 768 ? a.ntiles : 768) : a.ntiles;
   const bool bk64 = gam_gemm16_bk() == 64 && a.K % 64 == 0 && (a.a_mode == 0 || a.conv_c % 64 == 0);
   if (!bk64 && a.K % 32 != 0) return hipErrorInvalidValue;
-#define GAM_L16(ACTV)                                                     \
-  if (bk64) gam_launch_gemm16_t<ACTV, 64>(a, grid, stream);               \
-  else gam_launch_gemm16_t<ACTV, 32>(a, grid, stream);
+  const bool ap = a.Ahi != nullptr;
+#define GAM_L16(ACTV)                                                             \
+  if (bk64) { if (ap) gam_launch_gemm16_t<ACTV, 64, true>(a, grid, stream);       \
+              else gam_launch_gemm16_t<ACTV, 64, false>(a, grid, stream); }       \
+  else      { if (ap) gam_launch_gemm16_t<ACTV, 32, true>(a, grid, stream);       \
+              else gam_launch_gemm16_t<ACTV, 32, false>(a, grid, stream); }
   switch (act) {
     case GAM_ACT_SILU: GAM_L16(GAM_ACT_SILU); break;
     case GAM_ACT_RELU: GAM_L16(GAM_ACT_RELU); break;

@@ -116,12 +116,12 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
  *                     (a = a_hi + a_lo, w = w_hi + w_lo; the a_lo.w_lo term, ~2^-22 relative,
  *                     is dropped): fp32-equivalent accuracy at several times the rate.
  * Default: GAM_GEMM_F16X3 (environment GAM_GEMM_MODE=f32 selects the other at gam_create).
- * The CTC / RNN-T head GEMMs and gam_op_gemm always use GAM_GEMM_F32. */
+ * The CTC / RNN-T head GEMMs always use GAM_GEMM_F32; gam_op_gemm follows the mode. */
 enum { GAM_GEMM_F32 = 0, GAM_GEMM_F16X3 = 1 };
 int gam_set_gemm_mode(gam_handle* h, int mode);
 int gam_get_gemm_mode(const gam_handle* h);
 
-/* Raw fp32 GEMM entry for kernel-level tests and the roofline bench:
+/* Raw GEMM entry for kernel-level tests and the roofline bench (arithmetic = current mode):
  * C[M,N] = act(A[M,K] . W[N,K]^T + bias) (act: 0 none, 1 SiLU, 2 ReLU); K % 32 == 0. */
 int gam_op_gemm(gam_handle* h, const float* A, const float* W, const float* bias, float* C,
                 int M, int N, int K, int act, void* stream);

@@ -1,17 +1,13 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
-R=$PWD
 mkdir -p gpurun_out
-export TMPDIR=/tmp
-( time timeout 900 python -m pytest tests -q -m gpu ) > gpurun_out/pytest_gpu.log 2>&1
-( timeout 300 python bench.py --steps 5 --warmup 2 ) > gpurun_out/bench.log 2>&1
-( GAM_F16_BK=64 timeout 300 python bench.py --steps 5 --warmup 2 --cpu-utts 0 ) > gpurun_out/bench_bk64.log 2>&1
-( timeout 300 python bench.py --steps 5 --warmup 2 --cpu-utts 0 --gemm f32 ) > gpurun_out/bench_f32.log 2>&1
-tail -25 gpurun_out/pytest_gpu.log
-for f in bench bench_bk64 bench_f32; do tail -1 gpurun_out/$f.log | python -c "
+( timeout 600 python -m pytest tests/test_hip_parity.py -q -m gpu -k "rnnt" ) > gpurun_out/pytest_gpu.log 2>&1
+( timeout 300 python bench.py --steps 3 --warmup 1 --cpu-utts 0 --model v2_rnnt ) > gpurun_out/bench_rnnt.log 2>&1
+tail -3 gpurun_out/pytest_gpu.log
+for f in bench_rnnt; do tail -1 gpurun_out/$f.log | python -c "
 import sys, json
 try:
     d = json.loads(sys.stdin.readline())
-    print('$f', d['value'], d['ms_per_step'], d.get('roofline'), d.get('kernel_classes_ms_per_step'), d.get('cpu_baseline'))
+    print('$f', d['value'], d['ms_per_step'], d.get('kernel_classes_ms_per_step'), d.get('tokens_decoded_per_step'))
 except Exception as e: print('$f', 'ERR', e)
 "; done
