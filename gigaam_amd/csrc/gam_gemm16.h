@@ -18,18 +18,23 @@
 // conflict-free ds_read_b128.
 #pragma once
 #include "gam_gemm.h"
+#include <type_traits>
 
 typedef _Float16 gam_half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 gam_half8 __attribute__((ext_vector_type(8)));
 typedef unsigned gam_u32x4 __attribute__((ext_vector_type(4)));
 
-template <int BK>
+template <int BK, int BM = 128>
 struct GamGemm16Cfg {
+  static constexpr int NT = 2 * BM;                      // threads: BM/64 x 2 waves of 64x64
   static constexpr int LD = BK + 8;                      // halfs per LDS row (80 B / 144 B: odd # of 16 B slots)
-  static constexpr int PLANE = 128 * LD;                 // halfs per plane
-  static constexpr int SMEM = 4 * PLANE * 2;             // bytes
-  static constexpr int A_F4 = 128 * BK / 4 / 256;        // float4 loads of A per thread per k-tile
-  static constexpr int W_CH = 128 * BK / 8 / 256;        // 16-byte chunks per thread per W plane per k-tile
+  static constexpr int APLANE = BM * LD;                 // halfs per A plane
+  static constexpr int WPLANE = 128 * LD;                // halfs per W plane
+  static constexpr int STAGE = 2 * (APLANE + WPLANE);    // halfs per LDS stage (4 planes)
+  static constexpr int SMEM = STAGE * 2;                 // bytes per stage
+  static constexpr int A_F4 = BM * BK / 4 / NT;          // float4 loads of A per thread per k-tile
+  static constexpr int A_CH = BM * BK / 8 / NT;          // 16-byte chunks per thread per A plane (plane input)
+  static constexpr int W_CH = 128 * BK / 8 / NT;         // 16-byte chunks per thread per W plane per k-tile
 };
 
 __device__ __forceinline__ void gam_split4(const f32x4 v, gam_half4& hi, gam_half4& lo) {
@@ -39,28 +44,25 @@ __device__ __forceinline__ void gam_split4(const f32x4 v, gam_half4& hi, gam_hal
                    (_Float16)(v.w - (float)h3)};
 }
 
-template <int ACT, int BK, bool AP>
-__global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gam_gemm_f16x3_kernel(GamGemmArgs g) {
+template <int ACT, int BK, bool AP, int BM, bool PIPE>
+__global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : (BK == 32 ? 3 : 2))) void gam_gemm_f16x3_kernel(GamGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) _Float16 gam_smem16[];
-  using Cfg = GamGemm16Cfg<BK>;
-  constexpr int BM = 128, BN = 128, LD = Cfg::LD;
+  using Cfg = GamGemm16Cfg<BK, BM>;
+  constexpr int BN = 128, LD = Cfg::LD, NT = Cfg::NT;
   _Float16* Ahi = gam_smem16;
-  _Float16* Alo = gam_smem16 + Cfg::PLANE;
-  _Float16* Whi = gam_smem16 + 2 * Cfg::PLANE;
-  _Float16* Wlo = gam_smem16 + 3 * Cfg::PLANE;
+  _Float16* Alo = gam_smem16 + Cfg::APLANE;
+  _Float16* Whi = gam_smem16 + 2 * Cfg::APLANE;
+  _Float16* Wlo = gam_smem16 + 2 * Cfg::APLANE + Cfg::WPLANE;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  // Persistent over output tiles: workgroup b takes tiles b, b + gridDim.x, ... (gridDim.x
-  // is a multiple of 8 whenever it is smaller than the tile count, so a workgroup stays on
-  // its XCD's tile range).  A finished tile's stores drain behind the next tile's loads.
   const int nbn = (g.N + BN - 1) / BN;
-  const int total = g.ntiles;
+  const int total = gridDim.x;
   const int q8 = total >> 3, r8 = total & 7;
-  for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
+  const int bid = blockIdx.x;
   const int xcd = bid & 7;
   const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int m0 = (lid / nbn) * BM;
@@ -69,13 +71,13 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gam_gemm_f16x3_kernel(G
   // ---- A staging: float4 index f = tid + 256*i over [128 rows][BK/4];  W staging: 16 B chunk
   //      c = tid + 256*i over [128 rows][BK/8] per plane
   // AP = true: A arrives as fp16 planes (16-byte chunks, like W); AP = false: fp32, split here
-  constexpr int AF = AP ? Cfg::W_CH : Cfg::A_F4, WC = Cfg::W_CH, F4R = AP ? BK / 8 : BK / 4, CHR = BK / 8;
+  constexpr int AF = AP ? Cfg::A_CH : Cfg::A_F4, WC = Cfg::W_CH, F4R = AP ? BK / 8 : BK / 4, CHR = BK / 8;
   constexpr int AEL = AP ? 8 : 4;   // elements per A staging item
   size_t a_off[AF];
   int a_lds[AF];
 #pragma unroll
   for (int i = 0; i < AF; ++i) {
-    const int f = tid + 256 * i;
+    const int f = tid + NT * i;
     const int row = f / F4R, c4 = (f % F4R) * AEL;
     int m = m0 + row;
     m = m < g.M ? m : g.M - 1;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gam_gemm_f16x3_kernel(G
   int w_lds[WC];
 #pragma unroll
   for (int i = 0; i < WC; ++i) {
-    const int c = tid + 256 * i;
+    const int c = tid + NT * i;
     const int row = c / CHR, part = (c % CHR) * 8;
     int n = n0 + row;
     n = n < g.N ? n : g.N - 1;
@@ -133,67 +135,149 @@ __global__ __launch_bounds__(256, BK == 32 ? 3 : 2) void gam_gemm_f16x3_kernel(G
       vl[i] = *reinterpret_cast<const gam_u32x4*>(g.Wlo + w_off[i] + k0);
     }
   };
-  auto lstore = [&]() {
+  auto lstore = [&](int buf) {
+    _Float16* ah = Ahi + buf * Cfg::STAGE;
+    _Float16* al = Alo + buf * Cfg::STAGE;
+    _Float16* wh = Whi + buf * Cfg::STAGE;
+    _Float16* wl = Wlo + buf * Cfg::STAGE;
     if constexpr (AP) {
 #pragma unroll
       for (int i = 0; i < AF; ++i) {
-        *reinterpret_cast<gam_u32x4*>(Ahi + a_lds[i]) = vah[i];
-        *reinterpret_cast<gam_u32x4*>(Alo + a_lds[i]) = val[i];
+        *reinterpret_cast<gam_u32x4*>(ah + a_lds[i]) = vah[i];
+        *reinterpret_cast<gam_u32x4*>(al + a_lds[i]) = val[i];
       }
     } else {
 #pragma unroll
       for (int i = 0; i < AF; ++i) {
         gam_half4 hi, lo;
         gam_split4(va[i], hi, lo);
-        *reinterpret_cast<gam_half4*>(Ahi + a_lds[i]) = hi;
-        *reinterpret_cast<gam_half4*>(Alo + a_lds[i]) = lo;
+        *reinterpret_cast<gam_half4*>(ah + a_lds[i]) = hi;
+        *reinterpret_cast<gam_half4*>(al + a_lds[i]) = lo;
       }
     }
 #pragma unroll
     for (int i = 0; i < WC; ++i) {
-      *reinterpret_cast<gam_u32x4*>(Whi + w_lds[i]) = vh[i];
-      *reinterpret_cast<gam_u32x4*>(Wlo + w_lds[i]) = vl[i];
+      *reinterpret_cast<gam_u32x4*>(wh + w_lds[i]) = vh[i];
+      *reinterpret_cast<gam_u32x4*>(wl + w_lds[i]) = vl[i];
     }
   };
 
 #define GAM_MF16(AV, BV, ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AV, BV, ACC, 0, 0, 0)
+#define GAM_K16(BUF, KS)                                                                                        \
+  {                                                                                                             \
+    const int o_ = (BUF) * Cfg::STAGE + (KS) * 16;                                                              \
+    const gam_half8 ah0 = *reinterpret_cast<const gam_half8*>(Ahi + o_ + fa);                                  \
+    const gam_half8 ah1 = *reinterpret_cast<const gam_half8*>(Ahi + o_ + fa + 32 * LD);                        \
+    const gam_half8 bh0 = *reinterpret_cast<const gam_half8*>(Whi + o_ + fb);                                  \
+    const gam_half8 bh1 = *reinterpret_cast<const gam_half8*>(Whi + o_ + fb + 32 * LD);                        \
+    GAM_MF16(ah0, bh0, acc00); GAM_MF16(ah0, bh1, acc01); GAM_MF16(ah1, bh0, acc10); GAM_MF16(ah1, bh1, acc11); \
+    const gam_half8 bl0 = *reinterpret_cast<const gam_half8*>(Wlo + o_ + fb);                                  \
+    const gam_half8 bl1 = *reinterpret_cast<const gam_half8*>(Wlo + o_ + fb + 32 * LD);                        \
+    GAM_MF16(ah0, bl0, acc00); GAM_MF16(ah0, bl1, acc01); GAM_MF16(ah1, bl0, acc10); GAM_MF16(ah1, bl1, acc11); \
+    const gam_half8 al0 = *reinterpret_cast<const gam_half8*>(Alo + o_ + fa);                                  \
+    const gam_half8 al1 = *reinterpret_cast<const gam_half8*>(Alo + o_ + fa + 32 * LD);                        \
+    GAM_MF16(al0, bh0, acc00); GAM_MF16(al0, bh1, acc01); GAM_MF16(al1, bh0, acc10); GAM_MF16(al1, bh1, acc11); \
+  }
   const int frag = (lane & 31) * LD + (lane >> 5) * 8;
   const int fa = wm * 64 * LD + frag, fb = wn * 64 * LD + frag;
-  gload(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();
-    lstore();
-    __syncthreads();
-    if (kt + 1 < nk) gload(kt + 1);
+  if constexpr (PIPE) {
+    // Two LDS stages, one barrier per k-tile.  While tile kt is multiplied, the registers that
+    // hold tile kt+1 are split / written to the other stage and immediately re-loaded with
+    // tile kt+2, one staging item after every third MFMA, so the VALU, ds_write and
+    // global_load issue slots fall into the shadow of MFMAs in flight.  (With separate load /
+    // store / multiply phases the co-resident workgroups run phase-aligned and the three costs
+    // add up: measured 614 + 369 + 163 us at K = 12288.)
+    static_assert(!AP && BK == 32, "pipelined variant: fp32 A, BK = 32");
+    auto item = [&](auto st, auto ld, int j, int sbuf, size_t ka, int k0) {
+      // staging item j: 0..AF-1 = A float4 j ; AF..AF+2*WC-1 = W chunk (hi/lo interleaved)
+      if (j < AF) {
+        if constexpr (decltype(st)::value) {
+          gam_half4 hi, lo;
+          gam_split4(va[j], hi, lo);
+          *reinterpret_cast<gam_half4*>(Ahi + sbuf * Cfg::STAGE + a_lds[j]) = hi;
+          *reinterpret_cast<gam_half4*>(Alo + sbuf * Cfg::STAGE + a_lds[j]) = lo;
+        }
+        if constexpr (decltype(ld)::value) va[j] = *reinterpret_cast<const f32x4*>(g.A + a_off[j] + ka);
+      } else {
+        const int c = (j - AF) >> 1;
+        if ((j - AF) & 1) {
+          if constexpr (decltype(st)::value) *reinterpret_cast<gam_u32x4*>(Wlo + sbuf * Cfg::STAGE + w_lds[c]) = vl[c];
+          if constexpr (decltype(ld)::value) vl[c] = *reinterpret_cast<const gam_u32x4*>(g.Wlo + w_off[c] + k0);
+        } else {
+          if constexpr (decltype(st)::value) *reinterpret_cast<gam_u32x4*>(Whi + sbuf * Cfg::STAGE + w_lds[c]) = vh[c];
+          if constexpr (decltype(ld)::value) vh[c] = *reinterpret_cast<const gam_u32x4*>(g.Whi + w_off[c] + k0);
+        }
+      }
+    };
+    auto body = [&](auto st, auto ld, int kt) {
+      const int cur = kt & 1, sbuf = cur ^ 1;
+      const int k0 = (kt + 2) * BK;
+      size_t ka = (size_t)k0;
+      if (g.a_mode != 0) {
+        const int tap = k0 / g.conv_c, c0 = k0 - tap * g.conv_c;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        ka = ((size_t)kh * g.conv_fp + kw) * (size_t)g.conv_c + c0;
+      }
+      constexpr int NI = AF + 2 * WC;   // 8 staging items over 24 MFMAs
+      static_assert(NI == 8, "item schedule below assumes 8 staging items");
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const gam_half8 ah0 = *reinterpret_cast<const gam_half8*>(Ahi + fa + ks * 16);
-      const gam_half8 ah1 = *reinterpret_cast<const gam_half8*>(Ahi + fa + 32 * LD + ks * 16);
-      const gam_half8 bh0 = *reinterpret_cast<const gam_half8*>(Whi + fb + ks * 16);
-      const gam_half8 bh1 = *reinterpret_cast<const gam_half8*>(Whi + fb + 32 * LD + ks * 16);
-      GAM_MF16(ah0, bh0, acc00); GAM_MF16(ah0, bh1, acc01); GAM_MF16(ah1, bh0, acc10); GAM_MF16(ah1, bh1, acc11);
-      const gam_half8 bl0 = *reinterpret_cast<const gam_half8*>(Wlo + fb + ks * 16);
-      const gam_half8 bl1 = *reinterpret_cast<const gam_half8*>(Wlo + fb + 32 * LD + ks * 16);
-      GAM_MF16(ah0, bl0, acc00); GAM_MF16(ah0, bl1, acc01); GAM_MF16(ah1, bl0, acc10); GAM_MF16(ah1, bl1, acc11);
-      const gam_half8 al0 = *reinterpret_cast<const gam_half8*>(Alo + fa + ks * 16);
-      const gam_half8 al1 = *reinterpret_cast<const gam_half8*>(Alo + fa + 32 * LD + ks * 16);
-      GAM_MF16(al0, bh0, acc00); GAM_MF16(al0, bh1, acc01); GAM_MF16(al1, bh0, acc10); GAM_MF16(al1, bh1, acc11);
+      for (int ks = 0; ks < 2; ++ks) {
+        const int o_ = cur * Cfg::STAGE + ks * 16;
+        const gam_half8 ah0 = *reinterpret_cast<const gam_half8*>(Ahi + o_ + fa);
+        const gam_half8 ah1 = *reinterpret_cast<const gam_half8*>(Ahi + o_ + fa + 32 * LD);
+        const gam_half8 bh0 = *reinterpret_cast<const gam_half8*>(Whi + o_ + fb);
+        const gam_half8 bh1 = *reinterpret_cast<const gam_half8*>(Whi + o_ + fb + 32 * LD);
+        const gam_half8 bl0 = *reinterpret_cast<const gam_half8*>(Wlo + o_ + fb);
+        const gam_half8 bl1 = *reinterpret_cast<const gam_half8*>(Wlo + o_ + fb + 32 * LD);
+        const gam_half8 al0 = *reinterpret_cast<const gam_half8*>(Alo + o_ + fa);
+        const gam_half8 al1 = *reinterpret_cast<const gam_half8*>(Alo + o_ + fa + 32 * LD);
+        GAM_MF16(ah0, bh0, acc00); GAM_MF16(ah0, bh1, acc01); GAM_MF16(ah1, bh0, acc10);
+        item(st, ld, ks * 4 + 0, sbuf, ka, k0);
+        GAM_MF16(ah1, bh1, acc11); GAM_MF16(ah0, bl0, acc00); GAM_MF16(ah0, bl1, acc01);
+        item(st, ld, ks * 4 + 1, sbuf, ka, k0);
+        GAM_MF16(ah1, bl0, acc10); GAM_MF16(ah1, bl1, acc11); GAM_MF16(al0, bh0, acc00);
+        item(st, ld, ks * 4 + 2, sbuf, ka, k0);
+        GAM_MF16(al0, bh1, acc01); GAM_MF16(al1, bh0, acc10); GAM_MF16(al1, bh1, acc11);
+        item(st, ld, ks * 4 + 3, sbuf, ka, k0);
+      }
+      __syncthreads();
+    };
+    using T_ = std::integral_constant<bool, true>;
+    using F_ = std::integral_constant<bool, false>;
+    gload(0);
+    lstore(0);
+    if (nk > 1) gload(1);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) body(T_{}, T_{}, kt);
+    if (kt + 1 < nk) { body(T_{}, F_{}, kt); ++kt; }
+    body(F_{}, F_{}, kt);
+  } else {
+    gload(0);
+    for (int kt = 0; kt < nk; ++kt) {
+      __syncthreads();
+      lstore(0);
+      __syncthreads();
+      if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) GAM_K16(0, ks);
     }
   }
+#undef GAM_K16
 #undef GAM_MF16
   gam_gemm_epilogue<ACT>(g, acc00, acc01, acc10, acc11, m0, n0, wm, wn, lane, g.wscale_inv);
-  }  // tile loop
 }
 
-template <int ACT, int BK, bool AP>
+template <int ACT, int BK, bool AP, int BM = 128, bool PIPE = false>
 static inline void gam_launch_gemm16_t(const GamGemmArgs& a, int grid, hipStream_t stream) {
   static bool attr_done = false;
+  constexpr int smem = GamGemm16Cfg<BK, BM>::SMEM * (PIPE ? 2 : 1);
+  auto kern = gam_gemm_f16x3_kernel<ACT, BK, AP, BM, PIPE>;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gam_gemm_f16x3_kernel<ACT, BK, AP>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, GamGemm16Cfg<BK>::SMEM);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_done = true;
   }
-  hipLaunchKernelGGL((gam_gemm_f16x3_kernel<ACT, BK, AP>), dim3(grid), dim3(256), GamGemm16Cfg<BK>::SMEM, stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * BM), smem, stream, a);
 }
 
 // fp32 -> (hi, lo) fp16 planes over a flat range (elementwise, HBM-bound: 4 B in, 4 B out)
@@ -218,30 +302,42 @@ static inline int gam_gemm16_bk() {
   return v;
 }
 
-static inline int gam_gemm16_persist() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("GAM_PERSIST");
-    v = e ? atoi(e) : 0;
-  }
-  return v;
-}
-
 static inline hipError_t gam_launch_gemm16(const GamGemmArgs& a_in, int act, hipStream_t stream) {
   GamGemmArgs a = a_in;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K <= 0 || a.Whi == nullptr || a.Wlo == nullptr) return hipErrorInvalidValue;
+  // 256x128 tiles (8 waves) move 0.75x the bytes per FLOP of 128x128 ones; used when the grid is
+  // still many rounds deep (the kernel is bound by L2->LDS operand traffic, not by the MFMA pipe)
+  static int bm256_min = -1;
+  if (bm256_min < 0) { const char* e = getenv("GAM_BM256_MIN"); bm256_min = e ? atoi(e) : 1000; }
+  const int t256 = gam_cdiv(a.M, 256) * gam_cdiv(a.N, 128);
+  const bool big = a.Ahi == nullptr && t256 >= bm256_min && a.K % 32 == 0;
+  if (big) {
+    a.ntiles = t256;
+    switch (act) {
+      case GAM_ACT_SILU: gam_launch_gemm16_t<GAM_ACT_SILU, 32, false, 256, false>(a, t256, stream); break;
+      case GAM_ACT_RELU: gam_launch_gemm16_t<GAM_ACT_RELU, 32, false, 256, false>(a, t256, stream); break;
+      default: gam_launch_gemm16_t<GAM_ACT_NONE, 32, false, 256, false>(a, t256, stream); break;
+    }
+    return hipGetLastError();
+  }
   a.ntiles = gam_cdiv(a.M, 128) * gam_cdiv(a.N, 128);
-  // 256 CUs x 3 resident workgroups
-  const int grid = gam_gemm16_persist() ? (a.ntiles < 768 ? a.ntiles : 768) : a.ntiles;
+  const int grid = a.ntiles;
   const bool bk64 = gam_gemm16_bk() == 64 && a.K % 64 == 0 && (a.a_mode == 0 || a.conv_c % 64 == 0);
   if (!bk64 && a.K % 32 != 0) return hipErrorInvalidValue;
   const bool ap = a.Ahi != nullptr;
-#define GAM_L16(ACTV)                                                             \
-  if (bk64) { if (ap) gam_launch_gemm16_t<ACTV, 64, true>(a, grid, stream);       \
-              else gam_launch_gemm16_t<ACTV, 64, false>(a, grid, stream); }       \
-  else      { if (ap) gam_launch_gemm16_t<ACTV, 32, true>(a, grid, stream);       \
-              else gam_launch_gemm16_t<ACTV, 32, false>(a, grid, stream); }
+  // Few tiles (< 2 per CU: short utterances, single clips): occupancy cannot hide the staging
+  // phases, the in-wave pipelined variant wins (M = 2008: 62 -> 72 TF); many tiles: three
+  // phase-separated workgroups per CU win (K = 3072: 285 vs 275 TF).  GAM_PIPE=0/1 forces one.
+  static int pipe_env = -2;
+  if (pipe_env == -2) { const char* e = getenv("GAM_PIPE"); pipe_env = e ? atoi(e) : -1; }
+  const bool pipe = pipe_env >= 0 ? pipe_env != 0 : grid <= 512;
+#define GAM_L16(ACTV)                                                                     \
+  if (bk64) { if (ap) gam_launch_gemm16_t<ACTV, 64, true>(a, grid, stream);               \
+              else gam_launch_gemm16_t<ACTV, 64, false>(a, grid, stream); }               \
+  else if (ap) gam_launch_gemm16_t<ACTV, 32, true>(a, grid, stream);                      \
+  else if (pipe) gam_launch_gemm16_t<ACTV, 32, false, 128, true>(a, grid, stream);        \
+  else gam_launch_gemm16_t<ACTV, 32, false, 128, false>(a, grid, stream);
   switch (act) {
     case GAM_ACT_SILU: GAM_L16(GAM_ACT_SILU); break;
     case GAM_ACT_RELU: GAM_L16(GAM_ACT_RELU); break;
