@@ -15,6 +15,7 @@
 
 #include "../../include/gigaam_hip.h"
 #include "gam_attn.h"
+#include "gam_attn16.h"
 #include "gam_common.h"
 #include "gam_convmod.h"
 #include "gam_decode.h"
@@ -824,7 +825,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       at.pbuf = rel ? h->pbuf.p : nullptr; at.pos_u = L.pos_u; at.pos_v = L.pos_v; at.ldp = D;
       {
         ProfScope ps(h, s, GAM_PF_ATTN, 4.0 * (double)B * H * (double)Tv * Tv * dk);
-        hipError_t e = gam_launch_attn(at, dk, s);
+        hipError_t e = gam_launch_attn_mode(at, dk, h->gemm_mode == GAM_GEMM_F16X3, s);
         if (e != hipSuccess) return fail(h, -2, "attention launch: %s", hipGetErrorString(e));
       }
       GamGemmArgs go = gemm_args(h->ctx.p, D, L.wo, L.bo, h->x.p, D, N, D, D);
@@ -998,6 +999,22 @@ int gam_op_gemm(gam_handle* h, const float* A, const float* W, const float* bias
   W16 w16;
   w16.hi = (_Float16*)h->op_planes.p; w16.lo = w16.hi + count + 8; w16.inv = 1.0f;
   return gemm(h, s, g, act, GAM_PF_GEMM, &w16);
+}
+
+int gam_op_attention(gam_handle* h, const float* q, const float* k, const float* v, float* ctx, const int32_t* lens, int B,
+                     int T, int H, void* stream) {
+  if (!h) return -1;
+  if (B <= 0 || T <= 0 || H <= 0) return fail(h, -1, "bad attention shape");
+  HIPCHK(h, hipSetDevice(h->device));
+  GamAttnArgs at;
+  memset(&at, 0, sizeof at);
+  const int D = H * GAM_ATT_DK;
+  at.q = q; at.k = k; at.v = v; at.ctx = ctx; at.lens = lens;
+  at.B = B; at.Ta = T; at.Tv = T; at.H = H; at.ldq = D; at.ldv = D; at.ldo = D;
+  at.scale = 1.0f / sqrtf((float)GAM_ATT_DK);
+  hipError_t e = gam_launch_attn_mode(at, GAM_ATT_DK, h->gemm_mode == GAM_GEMM_F16X3, (hipStream_t)stream);
+  if (e != hipSuccess) return fail(h, -2, "attention launch: %s", hipGetErrorString(e));
+  return 0;
 }
 
 int gam_set_gemm_mode(gam_handle* h, int mode) {

@@ -29,7 +29,7 @@ struct GamAttnArgs {
   const int* lens;  // valid frames per utterance (keys), or null = no mask
   int B, Ta, Tv, H;
   long ldq, ldv, ldo;
-  float scale;
+  float scale;      // 1/sqrt(d_k); the kernels work in the log2 domain (scale * log2 e, v_exp_f32)
   // relative-position variant (v1 models, reference encoder.py:191-228):
   //   scores[i,j] = ((q_i + u).k_j + (q_i + v).P(i - j)) / sqrt(d_k),  P(r) = W_pos.pe(r)
   const float* pbuf;   // [2*Tv-1, ldp]: row n <-> relative position n - (Tv-1); head h at column h*dk
@@ -40,6 +40,7 @@ struct GamAttnArgs {
 
 template <bool REL>
 __global__ __launch_bounds__(256) void gam_attn_f32_kernel(GamAttnArgs a) {
+  a.scale *= 1.44269504088896341f;   // softmax via 2^x: p = 2^(s*log2e - m)
   __shared__ __attribute__((aligned(16))) float Ks[GAM_ATT_KT * GAM_ATT_KLD];
   __shared__ __attribute__((aligned(16))) float Vt[GAM_ATT_DK * GAM_ATT_VLD];
   __shared__ float Gs[REL ? 4 * 80 * 17 : 1];   // per wave: (q+v).P for 80 relative positions x 16 queries
@@ -173,14 +174,14 @@ __global__ __launch_bounds__(256) void gam_attn_f32_kernel(GamAttnArgs a) {
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mnew = fmaxf(mrun[j], mx);   // finite: key kt0 < klen is in this tile
-      alpha[j] = expf(mrun[j] - mnew);
+      alpha[j] = __builtin_amdgcn_exp2f(mrun[j] - mnew);
       mrun[j] = mnew;
       float ps = 0.f;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = expf(st[kb][j][r] - mnew);
+          const float p = __builtin_amdgcn_exp2f(st[kb][j][r] - mnew);
           st[kb][j][r] = p;
           ps += p;
         }

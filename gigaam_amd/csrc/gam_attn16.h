@@ -1,0 +1,224 @@
+// gam_attn16.h -- the fused attention of gam_attn.h with both small GEMMs evaluated as
+// three-term fp16 splits on the fp16 matrix cores (see gam_gemm16.h for the numerics):
+//   S^T = K.Q^T        ~  K_hi.Q_hi + K_hi.Q_lo + K_lo.Q_hi
+//   O^T = V^T.P^T      ~  V_hi.P_hi + V_hi.P_lo + V_lo.P_hi        (fp32 accumulate)
+// d_k = 48 is contracted as one v_mfma_f32_16x16x32_f16 (d 0..31) + one
+// v_mfma_f32_16x16x16_f16 (d 32..47); keys are contracted 32 at a time, the k-slot order
+// (e < 4: key block 2c, e >= 4: key block 2c+1) chosen so that a lane's eight S^T
+// accumulator registers of two neighbouring key blocks ARE its B operand -- P still never
+// leaves the registers.  Softmax statistics, masking and the rescale stay fp32.
+// K and V^T tiles are split once while they are staged into LDS (fp16 planes, rows padded to
+// an odd number of 16-byte slots).  Same work decomposition as gam_attn_f32_kernel.
+#pragma once
+#include "gam_attn.h"
+#include "gam_gemm16.h"
+
+#define GAM_A16_KLD 56   // halfs per K-plane row  (112 B = 7 x 16 B)
+#define GAM_A16_VLD 72   // halfs per V^T-plane row (144 B = 9 x 16 B)
+
+__device__ __forceinline__ void gam_split8(const float (&v)[8], gam_half8& hi, gam_half8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const _Float16 h = (_Float16)v[i];
+    hi[i] = h;
+    lo[i] = (_Float16)(v[i] - (float)h);
+  }
+}
+
+__global__ __launch_bounds__(256) void gam_attn_f16x3_kernel(GamAttnArgs a) {
+  a.scale *= 1.44269504088896341f;   // softmax via 2^x: p = 2^(s*log2e - m)
+  __shared__ __attribute__((aligned(16))) _Float16 Kh[GAM_ATT_KT * GAM_A16_KLD];
+  __shared__ __attribute__((aligned(16))) _Float16 Kl[GAM_ATT_KT * GAM_A16_KLD];
+  __shared__ __attribute__((aligned(16))) _Float16 Vh[GAM_ATT_DK * GAM_A16_VLD];
+  __shared__ __attribute__((aligned(16))) _Float16 Vl[GAM_ATT_DK * GAM_A16_VLD];
+  constexpr int DK = GAM_ATT_DK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  int klen = a.Tv;
+  if (a.lens != nullptr) { const int l = a.lens[b]; klen = l < a.Tv ? l : a.Tv; }
+  const size_t rowbase = (size_t)b * a.Ta;
+  const int qw0 = blockIdx.x * 128 + wave * 32;
+
+  // Q fragments (B operand of S^T), pre-scaled: x32 part d = 8*lg .. +7, x16 part d = 32 + 4*lg .. +3
+  gam_half8 qh32[2], ql32[2];
+  gam_half4 qh16[2], ql16[2];
+  int qrow[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int qi = qw0 + j * 16 + li;
+    qrow[j] = qi;
+    const int qc = qi < a.Ta ? qi : a.Ta - 1;
+    const float* qp = a.q + (rowbase + qc) * a.ldq + h * DK;
+    const float4 q0 = *reinterpret_cast<const float4*>(qp + 8 * lg);
+    const float4 q1 = *reinterpret_cast<const float4*>(qp + 8 * lg + 4);
+    const float4 q2 = *reinterpret_cast<const float4*>(qp + 32 + 4 * lg);
+    const float v8[8] = {q0.x * a.scale, q0.y * a.scale, q0.z * a.scale, q0.w * a.scale,
+                         q1.x * a.scale, q1.y * a.scale, q1.z * a.scale, q1.w * a.scale};
+    gam_split8(v8, qh32[j], ql32[j]);
+    const f32x4 v4 = {q2.x * a.scale, q2.y * a.scale, q2.z * a.scale, q2.w * a.scale};
+    gam_split4(v4, qh16[j], ql16[j]);
+  }
+
+  f32x4 o[3][2];
+#pragma unroll
+  for (int d = 0; d < 3; ++d)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) o[d][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float mrun[2] = {-INFINITY, -INFINITY};
+  float lsum[2] = {0.f, 0.f};
+
+  for (int kt0 = 0; kt0 < klen; kt0 += GAM_ATT_KT) {
+    // ---- stage K [64][48] and V^T [48][64] as fp16 hi/lo planes ----
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int idx = tid + i * 256;       // 0..767
+      const int kr = idx / 12, c4 = (idx - kr * 12) * 4;
+      int key = kt0 + kr;
+      key = key < a.Ta ? key : a.Ta - 1;
+      const float4 kv = *reinterpret_cast<const float4*>(a.k + (rowbase + key) * a.ldq + h * DK + c4);
+      gam_half4 hi, lo;
+      gam_split4((f32x4){kv.x, kv.y, kv.z, kv.w}, hi, lo);
+      *reinterpret_cast<gam_half4*>(&Kh[kr * GAM_A16_KLD + c4]) = hi;
+      *reinterpret_cast<gam_half4*>(&Kl[kr * GAM_A16_KLD + c4]) = lo;
+    }
+    // V^T: one item = 2 neighbouring keys x 4 channels -> per channel one 4-byte write per plane
+    for (int it = tid; it < 32 * 12; it += 256) {
+      const int kp = it / 12, c4 = (it - kp * 12) * 4;
+      int k0 = kt0 + 2 * kp, k1 = k0 + 1;
+      k0 = k0 < a.Ta ? k0 : a.Ta - 1;
+      k1 = k1 < a.Ta ? k1 : a.Ta - 1;
+      const float4 v0 = *reinterpret_cast<const float4*>(a.v + (rowbase + k0) * a.ldv + h * DK + c4);
+      const float4 v1 = *reinterpret_cast<const float4*>(a.v + (rowbase + k1) * a.ldv + h * DK + c4);
+      gam_half4 h0, l0, h1, l1;
+      gam_split4((f32x4){v0.x, v0.y, v0.z, v0.w}, h0, l0);
+      gam_split4((f32x4){v1.x, v1.y, v1.z, v1.w}, h1, l1);
+      typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        *reinterpret_cast<half2_t*>(&Vh[(c4 + e) * GAM_A16_VLD + 2 * kp]) = (half2_t){h0[e], h1[e]};
+        *reinterpret_cast<half2_t*>(&Vl[(c4 + e) * GAM_A16_VLD + 2 * kp]) = (half2_t){l0[e], l1[e]};
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T[kb][j] = K_kb . Q_j^T  (6 MFMAs per 16x16 tile) ----
+    f32x4 st[4][2];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const int ko = (kb * 16 + li) * GAM_A16_KLD;
+      const gam_half8 kh32 = *reinterpret_cast<const gam_half8*>(&Kh[ko + 8 * lg]);
+      const gam_half8 kl32 = *reinterpret_cast<const gam_half8*>(&Kl[ko + 8 * lg]);
+      const gam_half4 kh16 = *reinterpret_cast<const gam_half4*>(&Kh[ko + 32 + 4 * lg]);
+      const gam_half4 kl16 = *reinterpret_cast<const gam_half4*>(&Kl[ko + 32 + 4 * lg]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // Two accumulator chains, one per instruction shape: a 4-pass 16x16x16 MFMA issued
+        // right behind an 8-pass 16x16x32 one ON THE SAME accumulator lost the 8-pass result
+        // (hipcc 7.2 / gfx950, observed: S came out without its K_hi.Q_hi term).  Same-shape
+        // dependent chains are safe (the GEMMs rely on them); the two sums are added on the VALU.
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 s16 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl32, qh32[j], s, 0, 0, 0);
+        s16 = __builtin_amdgcn_mfma_f32_16x16x16f16(kl16, qh16[j], s16, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh32, ql32[j], s, 0, 0, 0);
+        s16 = __builtin_amdgcn_mfma_f32_16x16x16f16(kh16, ql16[j], s16, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh32, qh32[j], s, 0, 0, 0);
+        s16 = __builtin_amdgcn_mfma_f32_16x16x16f16(kh16, qh16[j], s16, 0, 0, 0);
+        s += s16;
+        st[kb][j] = s;
+      }
+    }
+
+    // ---- key mask + online softmax (fp32, per query = per lane column) ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt0 + kb * 16 + lg * 4 + r;
+          float s = st[kb][j][r];
+          s = key < klen ? s : -INFINITY;
+          st[kb][j][r] = s;
+          mx = fmaxf(mx, s);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(mrun[j], mx);   // finite: key kt0 < klen is in this tile
+      const float alpha = __builtin_amdgcn_exp2f(mrun[j] - mnew);
+      mrun[j] = mnew;
+      float ps = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(st[kb][j][r] - mnew);
+          st[kb][j][r] = p;
+          ps += p;
+        }
+      lsum[j] = lsum[j] * alpha + ps;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        o[d][j][0] *= alpha; o[d][j][1] *= alpha;
+        o[d][j][2] *= alpha; o[d][j][3] *= alpha;
+      }
+    }
+
+    // ---- O^T[d][j] += V^T_d . P_j^T over 32-key chunks: slot (lg, e) = key (2c + (e>>2))*16 + 4*lg + (e&3) ----
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      gam_half8 ph[2], pl[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float p8[8] = {st[2 * c][j][0], st[2 * c][j][1], st[2 * c][j][2], st[2 * c][j][3],
+                             st[2 * c + 1][j][0], st[2 * c + 1][j][1], st[2 * c + 1][j][2], st[2 * c + 1][j][3]};
+        gam_split8(p8, ph[j], pl[j]);
+      }
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int vo = (d * 16 + li) * GAM_A16_VLD + 4 * lg;
+        const gam_half4 vh0 = *reinterpret_cast<const gam_half4*>(&Vh[vo + (2 * c) * 16]);
+        const gam_half4 vh1 = *reinterpret_cast<const gam_half4*>(&Vh[vo + (2 * c + 1) * 16]);
+        const gam_half4 vl0 = *reinterpret_cast<const gam_half4*>(&Vl[vo + (2 * c) * 16]);
+        const gam_half4 vl1 = *reinterpret_cast<const gam_half4*>(&Vl[vo + (2 * c + 1) * 16]);
+        const gam_half8 vh = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
+        const gam_half8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          o[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[j], o[d][j], 0, 0, 0);
+          o[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[j], o[d][j], 0, 0, 0);
+          o[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[j], o[d][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane (query li, group lg) holds O^T rows d = dt*16 + 4*lg + r ----
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float l = lsum[j];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;   // klen == 0 -> zeros
+    if (qrow[j] < a.Ta) {
+      float* op = a.ctx + (rowbase + qrow[j]) * a.ldo + h * DK + 4 * lg;
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        *reinterpret_cast<float4*>(op + 16 * d) =
+            make_float4(o[d][j][0] * inv, o[d][j][1] * inv, o[d][j][2] * inv, o[d][j][3] * inv);
+    }
+  }
+}
+
+// split = true: fp16-split MFMA path (rotary / plain SDPA only); the relative-position
+// variant always runs the fp32-MFMA kernel
+static inline hipError_t gam_launch_attn_mode(const GamAttnArgs& a, int dk, bool split, hipStream_t s) {
+  if (!split || a.pbuf != nullptr) return gam_launch_attn(a, dk, s);
+  if (dk != GAM_ATT_DK) return hipErrorInvalidValue;
+  dim3 grid(gam_cdiv(a.Ta, 128), a.H, a.B);
+  hipLaunchKernelGGL(gam_attn_f16x3_kernel, grid, dim3(256), 0, s, a);
+  return hipGetLastError();
+}

@@ -229,6 +229,17 @@ class HipEngine:
         self._check(rc, "gam_op_gemm")
         return out
 
+    def op_attention(self, q: Tensor, k: Tensor, v: Tensor, lens: Optional[Tensor] = None) -> Tensor:
+        """q, k, v [B,T,H*48] -> ctx [B,T,H*48]; keys >= lens[b] are masked."""
+        q, k, v = (self._dev(t, torch.float32) for t in (q, k, v))
+        b, t, d = q.shape
+        lens_d = None if lens is None else self._dev(lens, torch.int32)
+        out = torch.empty_like(q)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gam_op_attention(self._h, _ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lens_d), b, t, d // 48, self._stream())
+        self._check(rc, "gam_op_attention")
+        return out
+
     # ------------------------------------------------------------------ profiling
     def profile_enable(self, on: bool = True) -> None:
         self._check(self.lib.gam_profile_enable(self._h, int(on)), "gam_profile_enable")

@@ -126,6 +126,12 @@ int gam_get_gemm_mode(const gam_handle* h);
 int gam_op_gemm(gam_handle* h, const float* A, const float* W, const float* bias, float* C,
                 int M, int N, int K, int act, void* stream);
 
+/* Raw attention entry for kernel-level tests: q, k, v, ctx f32 [B*T, H*48] token-major
+ * (head h = columns 48h..48h+47), lens i32 [B] valid keys per utterance or NULL (no mask);
+ * ctx = softmax(q.k^T / sqrt(48) over keys < len).v per head (arithmetic = current mode). */
+int gam_op_attention(gam_handle* h, const float* q, const float* k, const float* v, float* ctx,
+                     const int32_t* lens, int B, int T, int H, void* stream);
+
 /* Per-kernel-class HIP-event timing on the launch stream (bench.py's roofline leg).
  * gam_profile_enable(h,1) starts collecting; gam_profile_read synchronises the events and
  * returns, for class `cls`, the summed milliseconds, launch count and algorithmic work

@@ -80,6 +80,7 @@ def check_model(model, n_layers, batch, secs, lens, seed_audio=11, deep=True):
     tag = f"{model}_l{n_layers}_b{batch}"
     wav, wlen = synth.synth_audio(batch, secs, seed=seed_audio, lengths=lens)
     eng = HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], cfg.get("head")), sd, torch.device("cuda:0"))
+    eng.set_gemm_mode(os.environ.get("GAM_CHECK_MODE", "f16x3"))
     with torch.no_grad():
         feat_o, flen_o = O.log_mel(wav, wlen, cfg["preprocessor"], sd["preprocessor.featurizer.0.spectrogram.window"],
                                    sd["preprocessor.featurizer.0.mel_scale.fb"])

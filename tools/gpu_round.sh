@@ -3,9 +3,8 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
 ( timeout 900 python -m pytest tests -q -m gpu ) > gpurun_out/pytest_gpu.log 2>&1
 ( timeout 300 python bench.py --steps 5 --warmup 2 ) > gpurun_out/bench.log 2>&1
-( timeout 300 python bench.py --steps 5 --warmup 2 --cpu-utts 0 --batch 1 --seconds 5 ) > gpurun_out/bench_b1.log 2>&1
-tail -4 gpurun_out/pytest_gpu.log
-for f in bench bench_b1; do tail -1 gpurun_out/$f.log | python -c "
+tail -6 gpurun_out/pytest_gpu.log
+for f in bench; do tail -1 gpurun_out/$f.log | python -c "
 import sys, json
 try:
     d = json.loads(sys.stdin.readline())
