@@ -164,16 +164,20 @@ def main():
         step()
     barrier_sync()
     if not args.no_profile:
-        eng.profile_enable(True)
+        eng.profile_enable(2)      # inside the timed region: events around the GEMM family only
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     barrier_sync()
     dt = max_over_ranks(time.perf_counter() - t0)
-    prof = None
+    prof = prof_all = None
     if not args.no_profile:
         prof = eng.profile_read()
-        eng.profile_enable(False)
+        eng.profile_enable(1)      # one extra, untimed step for the per-class breakdown
+        step()
+        torch.cuda.synchronize()
+        prof_all = eng.profile_read()
+        eng.profile_enable(0)
 
     if rank != 0:
         if n_ranks > 1:
@@ -212,14 +216,22 @@ def main():
         else:
             # every algorithmic FLOP costs three fp16 MFMA FLOPs (hi.hi + hi.lo + lo.hi)
             kern, peak, issued = "gam_gemm_f16x3_kernel (3x v_mfma_f32_32x32x16_f16 per product; plain + implicit-GEMM conv)", F16_MFMA_PEAK_TFLOPS, 3.0 * ach
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.gemm}.json")
+        if args.model == "v2_ctc" and args.batch == 32 and args.seconds == 20.0 and os.path.exists(tpath):
+            tj = json.load(open(tpath))       # committed rocprofv3 PMC passes of this same command
+            traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), os.path.relpath(tpath, ROOT)
+        alg_bytes = sum(prof[k].get("bytes", 0.0) for k in fam)
         line["roofline"] = {
             "kernel": kern, "bound": "mfma", "achieved": round(issued, 2), "peak": peak, "unit": "TFLOP/s",
-            "frac": round(issued / peak, 4), "traffic": None, "algorithmic_tflops": round(ach, 2),
+            "frac": round(issued / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": round(alg_bytes / max(1, n)), "algorithmic_tflops": round(ach, 2),
             "launches_per_step": n // max(1, args.steps), "avg_launch_ms": round(ms / max(1, n), 4),
             "algorithmic_gflop_per_step": round(flop / args.steps / 1e9, 1),
             "share_of_step_time": round(ms / args.steps / ms_step, 3),
         }
-        line["kernel_classes_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]}
+        line["kernel_classes_ms_per_step"] = {k: round(v["ms"], 3) for k, v in prof_all.items() if v["launches"]}
+        line["kernel_classes_note"] = "HIP-event time per class from one extra untimed step"
         whole = FLOP_PER_UTT_20S_V2 * (args.seconds / 20.0) * args.batch * n_ranks / (ms_step * 1e-3) / 1e12
         line["whole_path_tflops"] = round(whole, 2)
     if n_ranks == 1 and args.cpu_utts > 0:

@@ -99,10 +99,11 @@ struct gam_handle {
   int lens_cap = 0;
 
   // profiler
-  bool prof_on = false;
+  int prof_on = 0;   // 0 off, 1 every launch, 2 GEMM family only
   std::vector<ProfEvent> prof_events;
   size_t prof_used = 0;
   double prof_work[GAM_PF_NCLASS] = {0};
+  double prof_bytes[GAM_PF_NCLASS] = {0};   // algorithmic operand + result bytes (GEMM classes)
   int64_t prof_launches[GAM_PF_NCLASS] = {0};
 };
 
@@ -225,7 +226,7 @@ struct ProfScope {
   hipStream_t s;
   ProfEvent* ev = nullptr;
   ProfScope(gam_handle* h_, hipStream_t s_, int cls, double work) : h(h_), s(s_) {
-    if (!h->prof_on) return;
+    if (!h->prof_on || (h->prof_on == 2 && cls != GAM_PF_GEMM && cls != GAM_PF_CONV2)) return;
     if (h->prof_used == h->prof_events.size()) {
       ProfEvent e;
       if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return;
@@ -245,6 +246,11 @@ struct ProfScope {
 int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls = GAM_PF_GEMM, const W16* w16 = nullptr) {
   GamGemmArgs a = a_in;
   ProfScope ps(h, s, cls, 2.0 * (double)a.M * (double)a.N * (double)a.K);
+  if (ps.ev) {   // unique bytes: A (overlapping rows counted once), W, C (+ residual)
+    const double abytes = a.a_mode == 0 ? ((double)(a.M - 1) * (double)std::min<long>(a.lda, a.K) + a.K) * 4.0
+                                        : (double)a.M / a.conv_f2 * 2.0 * a.conv_fp * a.conv_c * 4.0;
+    h->prof_bytes[cls] += abytes + 4.0 * a.N * a.K + 4.0 * a.M * a.N * (a.R ? 2.0 : 1.0);
+  }
   hipError_t e;
   if (h->gemm_mode == 1 && w16 != nullptr && w16->hi != nullptr) {
     a.Whi = w16->hi; a.Wlo = w16->lo; a.wscale_inv = w16->inv;
@@ -1027,9 +1033,15 @@ int gam_get_gemm_mode(const gam_handle* h) { return h ? h->gemm_mode : -1; }
 
 int gam_profile_enable(gam_handle* h, int on) {
   if (!h) return -1;
-  h->prof_on = on != 0;
+  h->prof_on = on;
   h->prof_used = 0;
-  for (int i = 0; i < GAM_PF_NCLASS; ++i) { h->prof_work[i] = 0; h->prof_launches[i] = 0; }
+  for (int i = 0; i < GAM_PF_NCLASS; ++i) { h->prof_work[i] = 0; h->prof_launches[i] = 0; h->prof_bytes[i] = 0; }
+  return 0;
+}
+
+int gam_profile_read_bytes(gam_handle* h, int cls, double* bytes) {
+  if (!h || cls < 0 || cls >= GAM_PF_NCLASS || !bytes) return -1;
+  *bytes = h->prof_bytes[cls];
   return 0;
 }
 

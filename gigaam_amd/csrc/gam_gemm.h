@@ -57,7 +57,7 @@ struct GamGemmArgs {
   // produced by gam_split_kernel or directly by the producing kernel
   const _Float16* Ahi;
   const _Float16* Alo;
-  int ntiles;           // set by the launcher (persistent tile loop of gam_gemm16.h)
+  int ntiles;           // set by the launcher
   float wscale_inv;     // 2^-wshift, applied to the accumulator in the epilogue
 };
 

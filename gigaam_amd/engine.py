@@ -241,7 +241,8 @@ class HipEngine:
         return out
 
     # ------------------------------------------------------------------ profiling
-    def profile_enable(self, on: bool = True) -> None:
+    def profile_enable(self, on=True) -> None:
+        """True/1: time every launch; 2: GEMM family only; False/0: off."""
         self._check(self.lib.gam_profile_enable(self._h, int(on)), "gam_profile_enable")
 
     def profile_read(self) -> Dict[str, Dict[str, float]]:
@@ -249,5 +250,7 @@ class HipEngine:
         for i, name in enumerate(_lib.PF_CLASSES):
             ms, n, work = C.c_double(), C.c_int64(), C.c_double()
             self._check(self.lib.gam_profile_read(self._h, i, C.byref(ms), C.byref(n), C.byref(work)), "gam_profile_read")
-            out[name] = {"ms": ms.value, "launches": int(n.value), "work": work.value}
+            nbytes = C.c_double()
+            self._check(self.lib.gam_profile_read_bytes(self._h, i, C.byref(nbytes)), "gam_profile_read_bytes")
+            out[name] = {"ms": ms.value, "launches": int(n.value), "work": work.value, "bytes": nbytes.value}
         return out

@@ -1,0 +1,78 @@
+"""Pinned-memory, double-buffered batch feeder (SURVEY.md §8f NEXT-1).
+
+The reference moves every longform batch to the device synchronously inside the loop
+(gigaam/model.py:230-233: ``wav_pad.to(device)``).  Here the zero-padded batch layout of
+``AudioDataset.collate`` (gigaam/utils.py:371-380) is assembled directly in a pinned host
+buffer and copied on a side stream while the previous batch is being transcribed, so the
+41 MB of a 32 x 20 s batch never sits on the critical path.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Iterator, List, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+
+def collate_lengths(segments: Sequence[Tensor]) -> Tuple[int, Tensor]:
+    lens = torch.tensor([int(s.shape[-1]) for s in segments], dtype=torch.int64)
+    return int(lens.max()) if len(segments) else 0, lens
+
+
+def batches(segments: Sequence[Tensor], batch_size: int) -> Iterator[List[Tensor]]:
+    for i in range(0, len(segments), batch_size):
+        yield list(segments[i:i + batch_size])
+
+
+class BatchFeeder:
+    """Iterate ``(wav_dev [B,L] f32 zero-padded, len_dev [B] i64)`` over ``segments`` in order."""
+
+    def __init__(self, segments: Sequence[Tensor], batch_size: int, device: torch.device):
+        self.segments = segments
+        self.batch_size = batch_size
+        self.device = torch.device(device)
+        self._copy_stream = torch.cuda.Stream(self.device)
+        max_b = min(batch_size, max(1, len(segments)))
+        max_l = max((int(s.shape[-1]) for s in segments), default=1)
+        self._pin = [torch.empty((max_b * max_l,), dtype=torch.float32).pin_memory() for _ in range(2)]
+        self._pin_len = [torch.empty((max_b,), dtype=torch.int64).pin_memory() for _ in range(2)]
+        self._ready = [None, None]   # H2D completion event of the copy last issued from pinned slot i
+
+    def _stage(self, slot: int, chunk: List[Tensor]):
+        b = len(chunk)
+        lmax, lens = collate_lengths(chunk)
+        if self._ready[slot] is not None:       # the copy issued two batches ago must have left this buffer
+            self._ready[slot].synchronize()
+        host = self._pin[slot][: b * lmax].view(b, lmax)      # contiguous pinned view of exactly this batch
+        host.zero_()
+        for j, c in enumerate(chunk):
+            host[j, : c.shape[-1]] = c
+        self._pin_len[slot][:b] = lens
+        with torch.cuda.stream(self._copy_stream):
+            # contiguous device tensors of exactly this batch's shape
+            wav = torch.empty((b, lmax), dtype=torch.float32, device=self.device)
+            wav.copy_(host, non_blocking=True)
+            ln = self._pin_len[slot][:b].to(self.device, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self._copy_stream)
+        self._ready[slot] = ready
+        return wav, ln, ready
+
+    def __iter__(self) -> Iterator[Tuple[Tensor, Tensor]]:
+        it = batches(self.segments, self.batch_size)
+        slot = 0
+        nxt = next(it, None)
+        staged = self._stage(slot, nxt) if nxt is not None else None
+        while staged is not None:
+            wav, ln, ready = staged
+            nxt = next(it, None)
+            other = slot ^ 1
+            if nxt is not None:
+                staged = self._stage(other, nxt)
+            else:
+                staged = None
+            torch.cuda.current_stream(self.device).wait_event(ready)
+            wav.record_stream(torch.cuda.current_stream(self.device))
+            ln.record_stream(torch.cuda.current_stream(self.device))
+            yield wav, ln
+            slot = other

@@ -166,15 +166,14 @@ class GigaAMASR(GigaAM):
         segments, boundaries = segment_audio_file(wav_file, SAMPLE_RATE, device=self._device, **kwargs)
         if not segments:
             return LongformTranscriptionResult(segments=[])
+        from .feeder import BatchFeeder
+
         result: List[Segment] = []
-        for i0 in range(0, len(segments), fr_batch_size):
-            chunk = segments[i0:i0 + fr_batch_size]
-            lens = torch.tensor([c.shape[-1] for c in chunk], dtype=torch.int64)
-            wav = torch.zeros(len(chunk), int(lens.max()), dtype=torch.float32)  # utils.AudioDataset.collate layout
-            for j, c in enumerate(chunk):
-                wav[j, : c.shape[-1]] = c
-            for j, (text, words) in enumerate(self.transcribe_batch(wav, lens, word_timestamps)):
-                start, end = boundaries[i0 + j]
+        idx = 0
+        for wav, lens in BatchFeeder(segments, fr_batch_size, self._device):   # pinned, double-buffered H2D
+            for text, words in self.transcribe_batch(wav, lens, word_timestamps):
+                start, end = boundaries[idx]
+                idx += 1
                 if word_timestamps:
                     shifted = [Word(text=w.text, start=round(w.start + start, 3), end=round(w.end + start, 3)) for w in words or []]
                     result.append(Segment(text=text, start=start, end=end, words=shifted))

@@ -133,13 +133,16 @@ int gam_op_attention(gam_handle* h, const float* q, const float* k, const float*
                      const int32_t* lens, int B, int T, int H, void* stream);
 
 /* Per-kernel-class HIP-event timing on the launch stream (bench.py's roofline leg).
- * gam_profile_enable(h,1) starts collecting; gam_profile_read synchronises the events and
+ * gam_profile_enable(h,1) starts collecting for every launch, (h,2) for the GEMM family only
+ * (fewer event packets inside a timed region), (h,0) stops; gam_profile_read synchronises the events and
  * returns, for class `cls`, the summed milliseconds, launch count and algorithmic work
  * (FLOP for GEMM/attention classes, bytes for the HBM-bound classes); it then resets. */
 enum { GAM_PF_GEMM = 0, GAM_PF_CONV2 = 1, GAM_PF_ATTN = 2, GAM_PF_NORM = 3, GAM_PF_CONVMOD = 4,
        GAM_PF_STEM = 5, GAM_PF_FRONTEND = 6, GAM_PF_DECODE = 7, GAM_PF_MISC = 8, GAM_PF_NCLASS = 9 };
 int gam_profile_enable(gam_handle* h, int on);
 int gam_profile_read(gam_handle* h, int cls, double* ms, int64_t* launches, double* work);
+/* algorithmic (unique operand + result) bytes of the timed launches of a GEMM class */
+int gam_profile_read_bytes(gam_handle* h, int cls, double* bytes);
 
 const char* gam_last_error(const gam_handle* h);
 

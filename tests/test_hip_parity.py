@@ -215,3 +215,22 @@ def test_model_api_transcribe(tmp_path):
     assert float((enc.cpu() - enc_o).abs().max()) < 1e-3
     out = model.transcribe_longform(wpath, speech_regions=[(0.0, 2.4), (2.6, 5.0)], min_duration=1.0, max_duration=2.5)
     assert len(out) == 2 and all(isinstance(s.text, str) for s in out)
+    # longform through the pinned double-buffered feeder == the same zero-padded batches fed by hand
+    # (batched vs single may legitimately differ: the frontend reflects at the BATCH end, as the reference does)
+    from gigaam_amd.vad_utils import segment_audio_file
+    regs = [(0.0, 1.1), (1.2, 2.4), (2.6, 3.3), (3.5, 5.0)]
+    kw = dict(speech_regions=regs, min_duration=0.5, max_duration=1.0)
+    a1 = model.transcribe_longform(wpath, fr_batch_size=1, **kw)
+    a3 = model.transcribe_longform(wpath, fr_batch_size=3, word_timestamps=True, **kw)
+    segs, bounds = segment_audio_file(wpath, 16000, **kw)
+    manual = []
+    for i0 in (0, 3):
+        chunk = segs[i0:i0 + 3]
+        lens = torch.tensor([c.shape[0] for c in chunk])
+        pad = torch.zeros(len(chunk), int(lens.max()))
+        for j, c in enumerate(chunk):
+            pad[j, : c.shape[0]] = c
+        manual += [t for t, _ in model.transcribe_batch(pad, lens)]
+    assert len(a1) == len(a3) == 4 and [s.text for s in a3] == manual and bounds == regs
+    assert [s.text for s in a1] == [model.transcribe_batch(c[None], torch.tensor([c.shape[0]]))[0][0] for c in segs]
+    assert [(s.start, s.end) for s in a3] == regs and a3.has_word_timestamps
