@@ -22,6 +22,7 @@
 #include "gam_frontend.h"
 #include "gam_gemm.h"
 #include "gam_gemm16.h"
+#include "gam_gemm_sp.h"
 #include "gam_norm.h"
 #include "gam_stem.h"
 
@@ -45,6 +46,7 @@ struct DevBuf {
 struct W16 {            // split-fp16 planes of one weight matrix (gam_gemm16.h)
   _Float16* hi = nullptr;
   _Float16* lo = nullptr;
+  _Float16* sp = nullptr;   // the same planes in the sp32 layout (gam_gemm_sp.h)
   float inv = 1.0f;
 };
 
@@ -94,7 +96,9 @@ struct gam_handle {
   // workspace (grow-only)
   DevBuf wavp, spec, img, c2, xin, y1, x, y, yr, hbuf, qk, vbuf, ctx, ubuf, zbuf, tok, logits, encp, pbuf, aplanes;
   int presplit = 0;   // GAM_PRESPLIT=1: split A in a pre-pass (experiment)
-  DevBuf op_planes; const float* op_w = nullptr; size_t op_count = 0;   // gam_op_gemm W-plane cache
+  int use_sp = 1;     // large-M GEMMs on the LDS-DMA sp32 kernel (GAM_SP=0 disables)
+  int sp_min_m = GAM_SP_MIN_M;   // GAM_SP_MIN_M overrides (tests force the sp path at small sizes)
+  DevBuf op_planes, op_sp; const float* op_w = nullptr; size_t op_count = 0;   // gam_op_gemm W-plane cache
   int* lens = nullptr;  // 4 * maxB ints: len0, len1, len2, enc_len
   int lens_cap = 0;
 
@@ -188,7 +192,7 @@ float half_bits_to_float(uint16_t x) { return half_to_float(x); }
 
 // W * 2^shift = hi + lo with hi, lo in fp16; the power-of-two scale puts max|W| near 2^8 so
 // that lo (~2^-11 |W|) stays in the normal fp16 range for all but negligible entries.
-int make_split(gam_handle* h, const std::vector<float>& w, W16& out) {
+int make_split(gam_handle* h, const std::vector<float>& w, W16& out, int K = 0) {
   float mx = 0.f;
   for (float v : w) mx = std::max(mx, fabsf(v));
   int shift = 0;
@@ -212,6 +216,21 @@ int make_split(gam_handle* h, const std::vector<float>& w, W16& out) {
   out.hi = (_Float16*)dh;
   out.lo = (_Float16*)dl;
   out.inv = ldexpf(1.0f, -shift);
+  if (K > 0 && K % 32 == 0 && w.size() % (size_t)K == 0) {
+    // the same planes in the sp32 layout: row n, k-block kb -> [hi x32 | lo x32] (gam_gemm_sp.h)
+    std::vector<uint16_t> sp(w.size() * 2);
+    for (size_t i = 0; i < w.size(); ++i) {
+      const size_t n = i / K, k = i % K;
+      const size_t o = n * 2 * (size_t)K + (k / 32) * 64 + (k % 32);
+      sp[o] = hi[i];
+      sp[o + 32] = lo[i];
+    }
+    void* ds = nullptr;
+    if (hipMalloc(&ds, sp.size() * 2 + 64) != hipSuccess) return -2;
+    h->owned.push_back(ds);
+    if (hipMemcpy(ds, sp.data(), sp.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return -2;
+    out.sp = (_Float16*)ds;
+  }
   return 0;
 }
 
@@ -254,6 +273,13 @@ int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls
   hipError_t e;
   if (h->gemm_mode == 1 && w16 != nullptr && w16->hi != nullptr) {
     a.Whi = w16->hi; a.Wlo = w16->lo; a.wscale_inv = w16->inv;
+    if (a.Asp != nullptr) {
+      if (w16->sp == nullptr) return fail(h, -2, "sp32 A without sp32 W planes");
+      a.Wsp = w16->sp;
+      e = gam_launch_gemm_sp(a, act, s);
+      if (e != hipSuccess) return fail(h, -2, "sp gemm launch (M=%d N=%d K=%d): %s", a.M, a.N, a.K, hipGetErrorString(e));
+      return 0;
+    }
     if (h->presplit && a.Ahi == nullptr && a.a_mode == 0) {
       const size_t count = ((size_t)(a.M - 1) * (size_t)a.lda + (size_t)a.K + 7) / 8 * 8;
       if (int r = ensure(h, h->aplanes, count + 64)) return r;
@@ -307,6 +333,8 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   h->device = device_id;
   *out = h;
   if (const char* e = getenv("GAM_PRESPLIT")) h->presplit = atoi(e);
+  if (const char* e = getenv("GAM_SP")) h->use_sp = atoi(e);
+  if (const char* e = getenv("GAM_SP_MIN_M")) h->sp_min_m = atoi(e);
   if (const char* e = getenv("GAM_GEMM_MODE")) h->gemm_mode = (strcmp(e, "f32") == 0) ? GAM_GEMM_F32 : GAM_GEMM_F16X3;
   const gam_config& c = h->cfg;
   if (c.d_model <= 0 || c.n_heads <= 0 || c.d_model % c.n_heads != 0)
@@ -439,7 +467,7 @@ int gam_finalize(gam_handle* h) {
       for (int ci = 0; ci < C; ++ci)
         for (int t = 0; t < 9; ++t) r[((size_t)n * 9 + t) * C + ci] = w2->data[((size_t)n * C + ci) * 9 + t];
     UP(h->c2_w, r);
-    if (make_split(h, r, h->s_c2)) return fail(h, -2, "split upload failed");
+    if (make_split(h, r, h->s_c2, 9 * C)) return fail(h, -2, "split upload failed");
     UP(h->c2_b, b2->data);
     // columns c*f2+f -> f*C+c (encoder.py:126-127 flattens channel-major)
     std::vector<float> l((size_t)D * C * h->f2);
@@ -448,7 +476,7 @@ int gam_finalize(gam_handle* h) {
       for (int ci = 0; ci < C; ++ci)
         for (int f = 0; f < f2; ++f) l[(size_t)n * C * f2 + (size_t)f * C + ci] = wl->data[(size_t)n * C * f2 + (size_t)ci * f2 + f];
     UP(h->lin_w, l);
-    if (make_split(h, l, h->s_lin)) return fail(h, -2, "split upload failed");
+    if (make_split(h, l, h->s_lin, C * h->f2)) return fail(h, -2, "split upload failed");
     UP(h->lin_b, bl->data);
   } else {
     const int ks = c.subs_kernel_size;
@@ -500,7 +528,7 @@ int gam_finalize(gam_handle* h) {
     NEED(b_, p + name + ".bias", nout);                                              \
     UP(dstw, w_->data);                                                              \
     UP(dstb, b_->data);                                                              \
-    if (make_split(h, w_->data, dsts)) return fail(h, -2, "split upload failed");    \
+    if (make_split(h, w_->data, dsts, nin)) return fail(h, -2, "split upload failed"); \
   }
     LINS_(L.ff1_w1, L.ff1_b1, L.s_ff1_w1, "feed_forward1.linear1", DFF, D);
     LINS_(L.ff1_w2, L.ff1_b2, L.s_ff1_w2, "feed_forward1.linear2", D, DFF);
@@ -515,7 +543,7 @@ int gam_finalize(gam_handle* h) {
       b.insert(b.end(), bk->data.begin(), bk->data.end());
       UP(L.wqk, w);
       UP(L.bqk, b);
-      if (make_split(h, w, L.s_wqk)) return fail(h, -2, "split upload failed");
+      if (make_split(h, w, L.s_wqk, D)) return fail(h, -2, "split upload failed");
     }
     LINS_(L.wv, L.bv, L.s_wv, "self_attn.linear_v", D, D);
     LINS_(L.wo, L.bo, L.s_wo, "self_attn.linear_out", D, D);
@@ -740,6 +768,12 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     HIPCHK(h, hipGetLastError());
   }
 
+  // Large batches: every big GEMM runs on the LDS-DMA kernel of gam_gemm_sp.h, and the kernels that
+  // produce its A operands (LayerNorm, SiLU epilogue, attention, conv module, stem) write them in the
+  // sp32 split layout instead of fp32 -- same bytes, no conversion pass.
+  const bool sp = h->gemm_mode == GAM_GEMM_F16X3 && h->use_sp && N >= h->sp_min_m && D % 32 == 0 && DFF % 32 == 0;
+  auto sp_a = [&](GamGemmArgs& g) { if (sp) g.Asp = reinterpret_cast<const _Float16*>(g.A); };
+
   // ------------------------------ stem ------------------------------
   if (conv2d) {
     const int FP = h->f1 + 1, F2 = h->f2;
@@ -749,6 +783,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       GamConv1Args a;
       a.feat = feat; a.img = h->img.p; a.w = h->c1_w; a.bias = h->c1_b; a.len0 = len0; a.len1 = len1;
       a.B = B; a.T = (int)T; a.F = F; a.Ta = Ta; a.FP = FP; a.C = C; a.T1 = T1;
+      a.img_split = sp && C % 32 == 0;
       ProfScope ps(h, s, GAM_PF_STEM, (double)B * 2 * Ta * FP * C * 4.0);
       hipLaunchKernelGGL(gam_conv2d1_kernel, dim3(2 * Ta, B), dim3(256), 0, s, a);
       HIPCHK(h, hipGetLastError());
@@ -758,8 +793,10 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     GamGemmArgs g = gemm_args(h->img.p, 0, h->c2_w, h->c2_b, h->c2.p, C, N * F2, C, 9 * C);
     g.a_mode = 1; g.conv_fp = FP; g.conv_c = C; g.conv_f2 = F2;
     g.lens = len2; g.rpb = Ta * F2; g.fdiv = F2;
+    if (sp && C % 32 == 0) { sp_a(g); g.c_split = 1; }
     if (int r = gemm(h, s, g, GAM_ACT_RELU, GAM_PF_CONV2, &h->s_c2)) return r;
     GamGemmArgs l = gemm_args(h->c2.p, (long)F2 * C, h->lin_w, h->lin_b, h->x.p, D, N, D, F2 * C);
+    if (sp && C % 32 == 0) sp_a(l);
     if (int r = gemm(h, s, l, GAM_ACT_NONE, GAM_PF_GEMM, &h->s_lin)) return r;
   } else {
     const int ks = c.subs_kernel_size, pad = (ks - 1) / 2;
@@ -796,6 +833,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
   if (nl > 0) {
     GamLnArgs a = ln;
     a.x = h->x.p; a.out1 = h->y.p; a.w1 = h->layers[0].ln_ff1_w; a.b1 = h->layers[0].ln_ff1_b;
+    a.split1 = sp;
     if (int r = layernorm(h, s, a, 0)) return r;
   }
   for (int li = 0; li < nl; ++li) {
@@ -803,20 +841,25 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     // --- FFN 1 (macaron half step) ---
     {
       GamGemmArgs g = gemm_args(h->y.p, D, L.ff1_w1, L.ff1_b1, h->hbuf.p, DFF, N, DFF, D);
+      sp_a(g); g.c_split = sp;
       if (int r = gemm(h, s, g, GAM_ACT_SILU, GAM_PF_GEMM, &L.s_ff1_w1)) return r;
       GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff1_w2, L.ff1_b2, h->x.p, D, N, D, DFF);
       g2.R = h->x.p; g2.ldr = D; g2.alpha = 0.5f;
+      sp_a(g2);
       if (int r = gemm(h, s, g2, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_ff1_w2)) return r;
     }
     // --- self attention ---
     {
       GamLnArgs a = ln;
       a.x = h->x.p; a.out1 = h->y.p; a.out2 = h->yr.p; a.w1 = L.ln_att_w; a.b1 = L.ln_att_b;
+      a.split1 = sp; a.split2 = sp;
       if (int r = layernorm(h, s, a, rel ? 0 : 1)) return r;
       // rotary: q,k project the rotated copy, v the plain one; rel_pos: all three project y
       GamGemmArgs gq = gemm_args(rel ? h->y.p : h->yr.p, D, L.wqk, L.bqk, h->qk.p, 2 * D, N, 2 * D, D);
+      sp_a(gq);
       if (int r = gemm(h, s, gq, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wqk)) return r;
       GamGemmArgs gv = gemm_args(h->y.p, D, L.wv, L.bv, h->vbuf.p, D, N, D, D);
+      sp_a(gv);
       if (int r = gemm(h, s, gv, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wv)) return r;
       if (rel) {  // P = linear_pos(pos_emb) for relative positions -(T'-1) .. T'-1 (no bias)
         const float* pe0 = h->rel_pe + (size_t)(c.pos_emb_max_len - 1 - (Tv - 1)) * D;
@@ -824,7 +867,8 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
         if (int r = gemm(h, s, gp, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wpos)) return r;
       }
       GamAttnArgs at;
-      at.q = h->qk.p; at.k = h->qk.p + D; at.v = h->vbuf.p; at.ctx = h->ctx.p;
+      memset(&at, 0, sizeof at);
+      at.q = h->qk.p; at.k = h->qk.p + D; at.v = h->vbuf.p; at.ctx = h->ctx.p; at.ctx_split = sp;
       at.lens = B > 1 ? len2 : nullptr;  // encoder.py:620-624: no mask at batch 1
       at.B = B; at.Ta = Ta; at.Tv = Tv; at.H = H; at.ldq = 2 * D; at.ldv = D; at.ldo = D;
       at.scale = 1.0f / sqrtf((float)dk);
@@ -836,18 +880,22 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       }
       GamGemmArgs go = gemm_args(h->ctx.p, D, L.wo, L.bo, h->x.p, D, N, D, D);
       go.R = h->x.p; go.ldr = D;
+      sp_a(go);
       if (int r = gemm(h, s, go, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wo)) return r;
     }
     // --- convolution module ---
     {
       GamLnArgs a = ln;
       a.x = h->x.p; a.out1 = h->y.p; a.w1 = L.ln_conv_w; a.b1 = L.ln_conv_b;
+      a.split1 = sp;
       if (int r = layernorm(h, s, a, 0)) return r;
       GamGemmArgs g1 = gemm_args(h->y.p, D, L.pw1_w, L.pw1_b, h->ubuf.p, 2 * D, N, 2 * D, D);
+      sp_a(g1);
       if (int r = gemm(h, s, g1, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_pw1)) return r;
       GamConvModArgs cm;
       cm.u = h->ubuf.p; cm.z = h->zbuf.p; cm.dw_w = L.dw_w; cm.dw_b = L.dw_b; cm.n_scale = L.cn_scale; cm.n_shift = L.cn_shift;
       cm.lens = len2; cm.B = B; cm.Ta = Ta; cm.Tv = Tv; cm.d = D; cm.ks = c.conv_kernel_size; cm.eps = 1e-5f;
+      cm.z_split = sp;
       {
         ProfScope ps(h, s, GAM_PF_CONVMOD, (double)N * D * 3 * 4.0);
         hipError_t e = gam_launch_convmod(cm, c.conv_norm_type == GAM_NORM_LAYER, s);
@@ -855,17 +903,21 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       }
       GamGemmArgs g2 = gemm_args(h->zbuf.p, D, L.pw2_w, L.pw2_b, h->x.p, D, N, D, D);
       g2.R = h->x.p; g2.ldr = D;
+      sp_a(g2);
       if (int r = gemm(h, s, g2, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_pw2)) return r;
     }
     // --- FFN 2 ---
     {
       GamLnArgs a = ln;
       a.x = h->x.p; a.out1 = h->y.p; a.w1 = L.ln_ff2_w; a.b1 = L.ln_ff2_b;
+      a.split1 = sp;
       if (int r = layernorm(h, s, a, 0)) return r;
       GamGemmArgs g = gemm_args(h->y.p, D, L.ff2_w1, L.ff2_b1, h->hbuf.p, DFF, N, DFF, D);
+      sp_a(g); g.c_split = sp;
       if (int r = gemm(h, s, g, GAM_ACT_SILU, GAM_PF_GEMM, &L.s_ff2_w1)) return r;
       GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff2_w2, L.ff2_b2, h->x.p, D, N, D, DFF);
       g2.R = h->x.p; g2.ldr = D; g2.alpha = 0.5f;
+      sp_a(g2);
       if (int r = gemm(h, s, g2, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_ff2_w2)) return r;
     }
     // --- norm_out (+ next layer's norm_feed_forward1) ---
@@ -874,6 +926,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       a.x = h->x.p; a.out1 = h->x.p; a.w1 = L.ln_out_w; a.b1 = L.ln_out_b;
       if (li + 1 < nl) {
         a.out2 = h->y.p; a.w2 = h->layers[li + 1].ln_ff1_w; a.b2 = h->layers[li + 1].ln_ff1_b;
+        a.split2 = sp;
         if (int r = layernorm(h, s, a, 2)) return r;
       } else {
         if (int r = layernorm(h, s, a, 0)) return r;
@@ -995,7 +1048,8 @@ int gam_op_gemm(gam_handle* h, const float* A, const float* W, const float* bias
   // split-fp16 mode: W planes are built on the device (unit scale) and cached per W pointer
   hipStream_t s = (hipStream_t)stream;
   const size_t count = ((size_t)N * K + 7) / 8 * 8;
-  if (h->op_w != W || h->op_count != count) {
+  const bool rebuilt = h->op_w != W || h->op_count != count;
+  if (rebuilt) {
     if (int r = ensure(h, h->op_planes, count + 64)) return r;
     _Float16* hi = (_Float16*)h->op_planes.p;
     hipLaunchKernelGGL(gam_split_kernel, dim3((int)std::min<size_t>((count / 4 + 255) / 256, 4096)), dim3(256), 0, s, W, hi,
@@ -1004,6 +1058,21 @@ int gam_op_gemm(gam_handle* h, const float* A, const float* W, const float* bias
   }
   W16 w16;
   w16.hi = (_Float16*)h->op_planes.p; w16.lo = w16.hi + count + 8; w16.inv = 1.0f;
+  if (h->use_sp && K % 32 == 0 && N % 4 == 0 && M >= h->sp_min_m) {
+    // sp32 operands: W converted once per pointer, A by a pre-pass (in the encoder the producing
+    // kernels write sp32 directly)
+    const size_t wn = (size_t)N * K, an = (size_t)M * K;
+    if (rebuilt || h->op_sp.cap < wn + 64) {
+      if (int r = ensure(h, h->op_sp, wn + 64)) return r;
+      hipLaunchKernelGGL(gam_to_sp32_kernel, dim3((int)std::min<size_t>((wn / 4 + 255) / 256, 4096)), dim3(256), 0, s, W,
+                         (_Float16*)h->op_sp.p, wn / 4);
+    }
+    if (int r = ensure(h, h->aplanes, an + 64)) return r;
+    hipLaunchKernelGGL(gam_to_sp32_kernel, dim3((int)std::min<size_t>((an / 4 + 255) / 256, 8192)), dim3(256), 0, s, A,
+                       (_Float16*)h->aplanes.p, an / 4);
+    w16.sp = (_Float16*)h->op_sp.p;
+    g.Asp = (const _Float16*)h->aplanes.p;
+  }
   return gemm(h, s, g, act, GAM_PF_GEMM, &w16);
 }
 

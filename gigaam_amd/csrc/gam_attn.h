@@ -26,6 +26,7 @@ struct GamAttnArgs {
   const float* k;   // same row stride
   const float* v;   // [B*Ta, ldv]
   float* ctx;       // [B*Ta, ldo]
+  int ctx_split;    // ctx in the sp32 GEMM-operand layout (ldo % 32 == 0)
   const int* lens;  // valid frames per utterance (keys), or null = no mask
   int B, Ta, Tv, H;
   long ldq, ldv, ldo;
@@ -220,11 +221,10 @@ __global__ __launch_bounds__(256) void gam_attn_f32_kernel(GamAttnArgs a) {
     l += __shfl_xor(l, 32, 64);
     const float inv = l > 0.f ? 1.0f / l : 0.f;   // klen == 0 -> zeros
     if (qrow[j] < a.Ta) {
-      float* op = a.ctx + (rowbase + qrow[j]) * a.ldo + h * DK + 4 * lg;
 #pragma unroll
       for (int d = 0; d < 3; ++d)
-        *reinterpret_cast<float4*>(op + 16 * d) =
-            make_float4(o[d][j][0] * inv, o[d][j][1] * inv, o[d][j][2] * inv, o[d][j][3] * inv);
+        gam_store4(a.ctx, (size_t)(rowbase + qrow[j]) * a.ldo, h * DK + 4 * lg + 16 * d, o[d][j][0] * inv, o[d][j][1] * inv,
+                   o[d][j][2] * inv, o[d][j][3] * inv, a.ctx_split);
     }
   }
 }

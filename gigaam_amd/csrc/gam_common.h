@@ -30,5 +30,43 @@ __device__ __forceinline__ float gam_sigmoid(float x) {
 __device__ __forceinline__ float gam_silu(float x) { return x * gam_sigmoid(x); }
 __device__ __forceinline__ float gam_sigmoid_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+typedef _Float16 gam_half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 gam_half8 __attribute__((ext_vector_type(8)));
+typedef unsigned gam_u32x4 __attribute__((ext_vector_type(4)));
+
+// x = hi + lo, hi = fp16(x), lo = fp16(x - hi): the split-fp16 operand format (gam_gemm16.h)
+__device__ __forceinline__ void gam_split4(const f32x4 v, gam_half4& hi, gam_half4& lo) {
+  const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y, h2 = (_Float16)v.z, h3 = (_Float16)v.w;
+  hi = (gam_half4){h0, h1, h2, h3};
+  lo = (gam_half4){(_Float16)(v.x - (float)h0), (_Float16)(v.y - (float)h1), (_Float16)(v.z - (float)h2),
+                   (_Float16)(v.w - (float)h3)};
+}
+
+// Activation stores.  `base` + `row_off` (elements, a multiple of 32) is the start of a row; c is
+// the column.  split = 0: plain fp32.  split = 1: the sp32 layout of gam_gemm_sp.h -- the row's
+// 32-element block c/32 holds [hi x32 | lo x32] fp16 in the 128 bytes the fp32 values would take.
+__device__ __forceinline__ void gam_store4(float* base, size_t row_off, int c, float x0, float x1, float x2, float x3,
+                                           int split) {   // c % 4 == 0
+  if (!split) {
+    *reinterpret_cast<f32x4*>(base + row_off + c) = (f32x4){x0, x1, x2, x3};
+  } else {
+    _Float16* p = reinterpret_cast<_Float16*>(base) + row_off * 2 + (c >> 5) * 64 + (c & 31);
+    gam_half4 hi, lo;
+    gam_split4((f32x4){x0, x1, x2, x3}, hi, lo);
+    *reinterpret_cast<gam_half4*>(p) = hi;
+    *reinterpret_cast<gam_half4*>(p + 32) = lo;
+  }
+}
+__device__ __forceinline__ void gam_store1(float* base, size_t row_off, int c, float x, int split) {
+  if (!split) {
+    base[row_off + c] = x;
+  } else {
+    _Float16* p = reinterpret_cast<_Float16*>(base) + row_off * 2 + (c >> 5) * 64 + (c & 31);
+    const _Float16 h = (_Float16)x;
+    p[0] = h;
+    p[32] = (_Float16)(x - (float)h);
+  }
+}
+
 // activation ids shared by host and device
 enum { GAM_ACT_NONE = 0, GAM_ACT_SILU = 1, GAM_ACT_RELU = 2 };

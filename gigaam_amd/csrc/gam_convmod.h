@@ -19,6 +19,7 @@ struct GamConvModArgs {
   const int* lens;     // valid frames per utterance
   int B, Ta, Tv, d, ks;
   float eps;
+  int z_split;   // z in the sp32 GEMM-operand layout
 };
 
 // ---- BatchNorm variant: block = 64 channels x 64 frames ----
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void gam_convmod_bn_kernel(GamConvModArgs a) {
     for (int k = 0; k < KS; ++k) acc = fmaf(w[k], tile[(tl + k) * 64 + cl], acc);
     acc += bias;
     const float y = acc * sc + sh;
-    a.z[(rowbase + t) * (size_t)a.d + c] = gam_silu(y);
+    gam_store1(a.z, (rowbase + t) * (size_t)a.d, c, gam_silu(y), a.z_split);
   }
 }
 
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(256) void gam_convmod_ln_kernel(GamConvModArgs a) {
 #pragma unroll
       for (int i = 0; i < TT; ++i) {
         const int t = t0 + i;
-        if (t < a.Ta) a.z[(rowbase + t) * (size_t)a.d + c] = gam_silu((y[ci][i] - mean[i]) * rstd[i] * g + be);
+        if (t < a.Ta) gam_store1(a.z, (rowbase + t) * (size_t)a.d, c, gam_silu((y[ci][i] - mean[i]) * rstd[i] * g + be), a.z_split);
       }
     }
   }

@@ -57,7 +57,12 @@ struct GamGemmArgs {
   // produced by gam_split_kernel or directly by the producing kernel
   const _Float16* Ahi;
   const _Float16* Alo;
+  // both operands in the sp32 layout of gam_gemm_sp.h (row pitch = lda / K elements, 4 B each)
+  const _Float16* Asp;
+  const _Float16* Wsp;
+  int c_split;          // write C in the sp32 layout (row pitch ldc elements) instead of fp32
   int ntiles;           // set by the launcher
+  int dbg;              // experiment switches (GAM_SP_DBG), 0 in production
   float wscale_inv;     // 2^-wshift, applied to the accumulator in the epilogue
 };
 

@@ -20,9 +20,6 @@
 #include "gam_gemm.h"
 #include <type_traits>
 
-typedef _Float16 gam_half4 __attribute__((ext_vector_type(4)));
-typedef _Float16 gam_half8 __attribute__((ext_vector_type(8)));
-typedef unsigned gam_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int BK, int BM = 128>
 struct GamGemm16Cfg {
@@ -37,12 +34,6 @@ struct GamGemm16Cfg {
   static constexpr int W_CH = 128 * BK / 8 / NT;         // 16-byte chunks per thread per W plane per k-tile
 };
 
-__device__ __forceinline__ void gam_split4(const f32x4 v, gam_half4& hi, gam_half4& lo) {
-  const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y, h2 = (_Float16)v.z, h3 = (_Float16)v.w;
-  hi = (gam_half4){h0, h1, h2, h3};
-  lo = (gam_half4){(_Float16)(v.x - (float)h0), (_Float16)(v.y - (float)h1), (_Float16)(v.z - (float)h2),
-                   (_Float16)(v.w - (float)h3)};
-}
 
 template <int ACT, int BK, bool AP, int BM, bool PIPE>
 __global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : (BK == 32 ? 3 : 2))) void gam_gemm_f16x3_kernel(GamGemmArgs g) {

@@ -1,0 +1,438 @@
+// gam_gemm_sp.h -- the large-M split-fp16 GEMM: 64*MT x 256 block tiles fed entirely by
+// LDS-DMA (global_load_lds_dwordx4), two 64 KB LDS stages, one barrier per k-tile.
+//
+// Same arithmetic as gam_gemm16.h (a.w ~= (a_hi.w_hi + a_hi.w_lo + a_lo.w_hi) 2^-s on
+// v_mfma_f32_32x32x16_f16, fp32 accumulate) but both operands arrive already split, in the
+// "sp32" layout that the producing kernels write instead of fp32:
+//
+//   element (row, k)  ->  halfs  row*2K + (k/32)*64 + (k%32)        hi = fp16(x)
+//                                row*2K + (k/32)*64 + 32 + (k%32)   lo = fp16(x - hi)
+//
+// i.e. the 4 bytes an fp32 element would occupy hold its (hi, lo) pair, regrouped so that one
+// row's share of a 32-deep k-tile is ONE 128-byte line [hi x32 | lo x32].  A k-tile of a block is
+// then (BM + 256) full lines; a wave-wide global_load_lds_dwordx4 moves 8 of them (1 KiB) straight
+// into LDS -- no staging registers, no ds_write pass, no conversion in the GEMM.  (The 128x128
+// register-staged kernel measured TD/TCP-bound on exactly that traffic: profiles/r01_f16x3_*.)
+//
+// LDS image: rows of 128 B (8 slots of 16 B), slot' = slot ^ ((row >> 1) & 7).  LDS-DMA writes
+// lane-linear, so the XOR is applied to the per-lane SOURCE address; fragment reads apply the same
+// XOR and every 16-lane service group of a ds_read_b128 (rows distinct mod 16) covers all 16 slots
+// of the 256-byte bank row exactly once: conflict-free without padding.
+//
+// 8 waves = 2 (M) x 4 (N); a wave owns (32*MT) x 64 outputs = MT x 2 MFMA tiles, 3 MFMAs per
+// tile per k16-step.  Bytes moved per FLOP are half those of the 128x128 kernel and the k-tile of
+// the next iteration lands while the current one is multiplied.  MT in {2,3,4} (BM = 128/192/256)
+// is picked per launch to minimise the tail of the last round of tiles.
+#pragma once
+#include "gam_gemm16.h"
+
+#define GAM_SP_MIN_M 2048   // below this the 128x128 kernels fill the chip better
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void gam_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    gam_static_for<N, I + 1>(f);
+  }
+}
+
+template <int MT, int NW>
+struct GamGemmSpCfg {
+  static constexpr int BM = 64 * MT;
+  static constexpr int BN = 64 * NW;
+  static constexpr int NWAVES = 2 * NW;                 // 2 (M) x NW (N) waves
+  static constexpr int NT = 64 * NWAVES;
+  static constexpr int A_BYTES = BM * 128;
+  static constexpr int W_BYTES = BN * 128;
+  static constexpr int STAGE = A_BYTES + W_BYTES;
+  static constexpr int SMEM = 2 * STAGE;
+  static constexpr int NAI = BM / 8 / NWAVES;   // A DMA pieces per wave per k-tile (8 rows x 128 B each)
+  static constexpr int NWI = BN / 8 / NWAVES;   // W DMA pieces per wave per k-tile
+};
+
+// one 32x32 accumulator tile -> C (fp32, or sp32 halves when g.c_split)
+template <int ACT>
+__device__ __forceinline__ void gam_gemm_epi_tile(const GamGemmArgs& g, const f32x16& acc, int mrow0, int ncol0,
+                                                  int lane, float accscale) {
+  const int col = ncol0 + (lane & 31);
+  const int lrow4 = 4 * (lane >> 5);
+  const bool colok = col < g.N;
+  const float bv = (g.bias != nullptr && colok) ? g.bias[col] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = mrow0 + (r & 3) + 8 * (r >> 2) + lrow4;
+    if (row >= g.M || !colok) continue;
+    bool masked = false;
+    long orow = row;
+    if (g.lens != nullptr || g.remap) {
+      const int bb = row / g.rpb, tt = row - bb * g.rpb;
+      if (g.lens != nullptr) masked = (tt / g.fdiv) >= g.lens[bb];
+      if (g.remap) {
+        if (tt >= g.rows_valid) continue;
+        orow = (long)bb * g.out_rpb + tt + g.out_shift;
+      }
+    }
+    float v = acc[r] * accscale + bv;
+    if (ACT == GAM_ACT_SILU) v = gam_silu(v);
+    if (ACT == GAM_ACT_RELU) v = fmaxf(v, 0.0f);
+    if (masked) v = 0.0f;
+    v *= g.alpha;
+    if (g.R != nullptr) v += g.R[orow * g.ldr + col];
+    if (g.c_split) {
+      _Float16* cp = reinterpret_cast<_Float16*>(g.C) + orow * (2 * g.ldc) + (col >> 5) * 64 + (col & 31);
+      const _Float16 h = (_Float16)v;
+      cp[0] = h;
+      cp[32] = (_Float16)(v - (float)h);
+    } else {
+      g.C[orow * g.ldc + col] = v;
+    }
+  }
+}
+
+template <int ACT, int MT, int NW>
+__global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(GamGemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gam_smem_sp[];
+  using Cfg = GamGemmSpCfg<MT, NW>;
+  constexpr int BM = Cfg::BM, BN = Cfg::BN, NAI = Cfg::NAI, NWI = Cfg::NWI, NWAVES = Cfg::NWAVES;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / NW, wn = wave % NW;
+
+  const int nbn = (g.N + BN - 1) / BN;
+  const int total = gridDim.x;
+  const int q8 = total >> 3, r8 = total & 7;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7;
+  const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int m0 = (lid / nbn) * BM;
+  const int n0 = (lid % nbn) * BN;
+
+  // ---- DMA sources.  Piece q of an operand = tile rows 8q .. 8q+7; this wave moves pieces
+  //      q = wave + NWAVES i.  Lane l -> row 8q + (l>>3), LDS slot' l&7, source slot (l&7) ^ ((row>>1)&7).
+  //      Addresses = wave-uniform tile base (SGPR pair) + 32-bit lane offset.
+  auto a_row_off = [&](int m) -> size_t {
+    m = m < g.M ? m : g.M - 1;
+    if (g.a_mode == 0) return (size_t)m * (size_t)g.lda;
+    const int fr = m / g.conv_f2, ff = m - fr * g.conv_f2;
+    return ((size_t)fr * 2 * g.conv_fp + 2 * ff) * (size_t)g.conv_c;
+  };
+  const size_t a_tile0 = a_row_off(m0);   // offsets grow with m, so every row offset is >= this one
+  const unsigned char* Ab = reinterpret_cast<const unsigned char*>(g.Asp) + a_tile0 * 4;
+  const unsigned char* Wb = reinterpret_cast<const unsigned char*>(g.Wsp) + (size_t)n0 * (size_t)g.K * 4;
+  unsigned a_src[NAI], w_src[NWI];
+#pragma unroll
+  for (int i = 0; i < NAI; ++i) {
+    const int row = 8 * (wave + NWAVES * i) + (lane >> 3);
+    const int slot = (lane & 7) ^ ((row >> 1) & 7);
+    a_src[i] = (unsigned)((a_row_off(m0 + row) - a_tile0) * 4) + slot * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < NWI; ++i) {
+    const int row = 8 * (wave + NWAVES * i) + (lane >> 3);
+    const int slot = (lane & 7) ^ ((row >> 1) & 7);
+    int n = n0 + row;
+    n = n < g.N ? n : g.N - 1;
+    w_src[i] = (unsigned)(n - n0) * (unsigned)g.K * 4u + slot * 16;
+  }
+
+  f32x16 acc[MT][2];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = g.K / 32;
+  // next k-tile to fetch, tracked incrementally (no divisions in the loop); it stops at the last tile
+  int d_kt = 0, d_c0 = 0, d_kw = 0, d_kh = 0;
+  auto dma_ka = [&]() -> size_t {   // byte offset of tile d_kt along an A row
+    if (g.a_mode == 0) return (size_t)d_kt * 128;
+    return (((size_t)d_kh * g.conv_fp + d_kw) * (size_t)g.conv_c + d_c0) * 4;
+  };
+  auto dma_advance = [&]() {
+    if (d_kt + 1 >= nk) return;
+    ++d_kt;
+    d_c0 += 32;
+    if (g.a_mode != 0 && d_c0 == g.conv_c) {
+      d_c0 = 0;
+      if (++d_kw == 3) { d_kw = 0; ++d_kh; }
+    }
+  };
+  auto issue = [&](int stage) {
+    unsigned char* sb = gam_smem_sp + stage * Cfg::STAGE + wave * 1024;
+    const unsigned char* ab = Ab + dma_ka();
+    const unsigned char* wb = Wb + (size_t)d_kt * 128;
+#pragma unroll
+    for (int i = 0; i < NAI; ++i)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(ab + a_src[i]), (lds_ptr_t)(sb + i * (NWAVES * 1024)), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NWI; ++i)
+      __builtin_amdgcn_global_load_lds((glb_ptr_t)(wb + w_src[i]), (lds_ptr_t)(sb + Cfg::A_BYTES + i * (NWAVES * 1024)), 16, 0, 0);
+    dma_advance();
+  };
+
+  // ---- fragment addressing: lane -> row (lane&31), k-half kg = lane>>5; slot = plane*4 + 2*ks + kg
+  const int sx = (lane >> 1) & 7;
+  const int kg = lane >> 5;
+  const int rowb = (lane & 31) * 128;
+  const int o_h0 = rowb + (((0 + kg) ^ sx) << 4), o_h1 = rowb + (((2 + kg) ^ sx) << 4);
+  const int o_l0 = rowb + (((4 + kg) ^ sx) << 4), o_l1 = rowb + (((6 + kg) ^ sx) << 4);
+  const int a_base = wm * (BM / 2) * 128;
+  const int w_base = Cfg::A_BYTES + wn * 64 * 128;
+
+  // Two fragment sets (k16-step 0 / 1 of a k-tile), two MFMA phases per k-tile:
+  //   phase 0: MFMAs on set 0, reading set 1 (same tile) in between
+  //   vmcnt(0) + lgkmcnt(0) + barrier      -- tile kt+1 landed everywhere, stage kt&1 has no reader left
+  //   phase 1: MFMAs on set 1, in between: read set 0 of tile kt+1, then DMA tile kt+2 -> stage kt&1
+  // Everything that is not an MFMA is issued one or two items at a time BETWEEN MFMAs: an LDS-DMA piece
+  // costs the issuing wave ~60+ cycles, and with the whole refill issued in one block after the barrier
+  // both waves of a SIMD sat in it together and the matrix pipe idled ~600 of every 3500 cycles
+  // (clock64 instrumentation, GAM_SP_DBG=4).  Fragment reads get >= 2/3 of a phase to land.
+  gam_half8 fah[2][MT], fal[2][MT], fbh[2][2], fbl[2][2];
+  constexpr int NM = 6 * MT;        // MFMAs per phase: 3 terms x MT x 2 tiles
+  constexpr int NR = 2 * MT + 4;    // fragment reads per set
+  constexpr int NG = NAI + NWI;     // DMA pieces per wave per k-tile
+  static_assert((NR + 1) / 2 + NG <= NM, "phase too short for its reads + DMA pieces");
+#define GAM_SPLD(P) (*reinterpret_cast<const gam_half8*>(P))
+  // (plain ifs on unrolled loop counters, not nested generic lambdas: those push the fragment arrays to scratch)
+#define GAM_SP_RDITEM(S, Q, ST, OH, OL)                                                           \
+  {                                                                                               \
+    const int q_ = (Q);                                                                           \
+    if (q_ < 2) fbh[S][q_ & 1] = GAM_SPLD((ST) + w_base + (q_ & 1) * 4096 + (OH));                 \
+    else if (q_ < MT + 2) fah[S][(q_ + MT - 2) % MT] = GAM_SPLD((ST) + a_base + ((q_ + MT - 2) % MT) * 4096 + (OH)); \
+    else if (q_ < MT + 4) fbl[S][(q_ - MT) & 1] = GAM_SPLD((ST) + w_base + ((q_ - MT) & 1) * 4096 + (OL)); \
+    else fal[S][(q_ + MT - 4) % MT] = GAM_SPLD((ST) + a_base + ((q_ + MT - 4) % MT) * 4096 + (OL)); \
+  }
+#define GAM_SP_MFMA(S, T)                                                                         \
+  {                                                                                               \
+    const int term_ = (T) / (2 * MT), i_ = ((T) % (2 * MT)) / 2, j_ = (T) & 1;                    \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term_ == 2 ? fal[S][i_] : fah[S][i_],    \
+                                                         term_ == 1 ? fbl[S][j_] : fbh[S][j_], acc[i_][j_], 0, 0, 0); \
+  }
+  // phase<S, DMA>: MFMAs of set S; reads of set 1-S from (rst, roh, rol); DMA pieces of the next tile -> stage istage
+  auto phase = [&](auto setc, auto dmac, const unsigned char* rst, int roh, int rol, int istage) {
+    constexpr int S = decltype(setc)::value, R = 1 - S;
+    constexpr bool DMA = decltype(dmac)::value;
+    constexpr int G0 = (NR + 1) / 2;   // first MFMA slot that carries a DMA piece
+    const unsigned char* ab = Ab;
+    const unsigned char* wb = Wb;
+    unsigned char* sb = gam_smem_sp;
+    if constexpr (DMA) {
+      ab = Ab + dma_ka();
+      wb = Wb + (size_t)d_kt * 128;
+      sb = gam_smem_sp + istage * Cfg::STAGE + wave * 1024;
+      dma_advance();
+    }
+#pragma unroll
+    for (int t = 0; t < NM; ++t) {
+      GAM_SP_MFMA(S, t);
+      if (2 * t < NR) GAM_SP_RDITEM(R, 2 * t, rst, roh, rol);
+      if (2 * t + 1 < NR) GAM_SP_RDITEM(R, 2 * t + 1, rst, roh, rol);
+      if (DMA && t >= G0 && t - G0 < NG) {
+        const int gi = t - G0;
+        if (gi < NAI)
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)(ab + a_src[gi % NAI]), (lds_ptr_t)(sb + gi * (NWAVES * 1024)), 16, 0, 0);
+        else
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)(wb + w_src[(gi - NAI + NWI) % NWI]),
+                                           (lds_ptr_t)(sb + Cfg::A_BYTES + (gi - NAI) * (NWAVES * 1024)), 16, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  using C0_ = std::integral_constant<int, 0>;
+  using C1_ = std::integral_constant<int, 1>;
+  using T_ = std::integral_constant<bool, true>;
+  using F_ = std::integral_constant<bool, false>;
+
+  long long t_bar = 0, t_mm0 = 0, t_mm1 = 0, t_start = 0, w_start = 0;
+  if (g.dbg & 4) { t_start = clock64(); w_start = wall_clock64(); }
+  issue(0);
+  issue(1);   // (nk == 1: fetches tile 0 again, unused)
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __syncthreads();   // both tiles have landed for every wave
+#pragma unroll
+  for (int q = 0; q < NR; ++q) GAM_SP_RDITEM(0, q, gam_smem_sp, o_h0, o_l0);
+  const int nk_run = (g.dbg & 2) ? 1 : nk;
+  for (int kt = 0; kt < nk_run; ++kt) {
+    const unsigned char* st = gam_smem_sp + (kt & 1) * Cfg::STAGE;
+    const unsigned char* sn = gam_smem_sp + ((kt & 1) ^ 1) * Cfg::STAGE;
+    long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    if (g.dbg & 4) c0 = clock64();
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): set 0 landed (read >= 2/3 of a phase ago)
+    phase(C0_{}, F_{}, st, o_h1, o_l1, 0);
+    if (g.dbg & 4) c1 = clock64();
+    // vmcnt(0) by hand: this wave's DMA pieces of tile kt+1 have landed (hipcc does not reliably order
+    // an LDS-DMA against the ds_reads behind a later barrier); lgkmcnt(0): set 1 is in registers
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();
+    if (g.dbg & 4) c2 = clock64();
+    // Unconditional (one copy of the MFMA stream; a second, DMA-less copy behind a branch made hipcc
+    // double-buffer the accumulators): past the end the set-0 reads fetch stale LDS that is never used
+    // and the DMA re-fetches the last k-tile into a stage nobody reads again (drained before the epilogue).
+    phase(C1_{}, T_{}, sn, o_h0, o_l0, kt & 1);
+    if (g.dbg & 4) { c3 = clock64(); t_mm0 += c1 - c0; t_bar += c2 - c1; t_mm1 += c3 - c2; }
+  }
+  if ((g.dbg & 4) && lane == 0 && (lid == 0 || lid == gridDim.x - 1)) {
+    // [total clk, total wall(100 MHz), phase 0, barrier, phase 1] of one wave
+    float* d = g.C + (size_t)(g.M - 1) * g.ldc + (lid == 0 ? 0 : 64) + wave * 8;
+    d[0] = (float)(clock64() - t_start); d[1] = (float)(wall_clock64() - w_start);
+    d[2] = (float)t_mm0; d[3] = (float)t_bar; d[4] = (float)t_mm1;
+    return;
+  }
+#undef GAM_SPLD
+#undef GAM_SP_RDITEM
+#undef GAM_SP_MFMA
+  // the last phases' stale set-0 reads and surplus DMA pieces must not race the scratch writes below
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __syncthreads();
+
+  const int mw = m0 + wm * (BM / 2), nw = n0 + wn * 64;
+  if ((g.dbg & 1) && acc[0][0][0] != 123.456f) return;
+
+  // ---- epilogue.  Each wave transposes its 32 x 64 slabs through a private LDS scratch (the stages
+  //      are dead: the last reads completed before the final barrier, no DMA is outstanding) so that
+  //      a lane owns 4 consecutive columns of a row: bias / residual / C move as 16-byte vectors,
+  //      4 rows x 256 B per instruction, and the per-row index math runs once per row.
+  constexpr int TLD = 68;   // floats per scratch row (272 B: rows of a read group fall on distinct banks)
+  float* T = reinterpret_cast<float*>(gam_smem_sp) + wave * (32 * TLD);
+  const int ecol = nw + (lane & 15) * 4;
+  const bool colok = ecol < g.N;   // N % 4 == 0 (launcher)
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (g.bias != nullptr && colok) bv = *reinterpret_cast<const f32x4*>(g.bias + ecol);
+  const float accscale = g.wscale_inv;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TLD + 32 * j + (lane & 31)] = acc[i][j][r];
+    // (same wave wrote and reads: only the LDS counter orders them, no barrier)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int lr = it * 4 + (lane >> 4);
+      const int row = mw + 32 * i + lr;
+      f32x4 v = *reinterpret_cast<const f32x4*>(T + lr * TLD + (lane & 15) * 4);
+      if (row >= g.M || !colok) continue;
+      bool masked = false;
+      long orow = row;
+      if (g.lens != nullptr || g.remap) {
+        const int bb = row / g.rpb, tt = row - bb * g.rpb;
+        if (g.lens != nullptr) masked = (tt / g.fdiv) >= g.lens[bb];
+        if (g.remap) {
+          if (tt >= g.rows_valid) continue;
+          orow = (long)bb * g.out_rpb + tt + g.out_shift;
+        }
+      }
+      v = v * accscale + bv;
+      if (ACT == GAM_ACT_SILU) { v.x = gam_silu(v.x); v.y = gam_silu(v.y); v.z = gam_silu(v.z); v.w = gam_silu(v.w); }
+      if (ACT == GAM_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (masked) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      v = v * g.alpha;
+      if (g.R != nullptr) v += *reinterpret_cast<const f32x4*>(g.R + orow * g.ldr + ecol);
+      if (g.c_split) {
+        _Float16* cp = reinterpret_cast<_Float16*>(g.C) + orow * (2 * g.ldc) + (ecol >> 5) * 64 + (ecol & 31);
+        gam_half4 hi, lo;
+        gam_split4(v, hi, lo);
+        *reinterpret_cast<gam_half4*>(cp) = hi;
+        *reinterpret_cast<gam_half4*>(cp + 32) = lo;
+      } else {
+        *reinterpret_cast<f32x4*>(g.C + orow * g.ldc + ecol) = v;
+      }
+    }
+  }
+}
+
+// the vectorised epilogue moves 16-byte pieces of bias / R / C rows
+static inline bool gam_gemm_sp_epilogue_ok(const GamGemmArgs& a) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  return a.N % 4 == 0 && a.ldc % 4 == 0 && al16(a.C) && (a.bias == nullptr || al16(a.bias)) &&
+         (a.R == nullptr || (a.ldr % 4 == 0 && al16(a.R)));
+}
+
+template <int ACT, int MT, int NW>
+static inline void gam_launch_gemm_sp_t(const GamGemmArgs& a, int grid, hipStream_t stream) {
+  static bool attr_done = false;
+  constexpr int smem = GamGemmSpCfg<MT, NW>::SMEM;
+  auto kern = gam_gemm_sp_kernel<ACT, MT, NW>;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * NW), smem, stream, a);
+}
+
+// Tile shape.  NW = 2: (64 MT) x 128 tiles, 4 waves, 2 workgroups per CU (80 KB LDS each at MT = 3):
+// the two run out of phase, so one's epilogue / barrier waits hide under the other's MFMAs.
+// NW = 4: (64 MT) x 256 tiles, 8 waves, 1 workgroup per CU: fewest bytes per FLOP, nothing hides
+// the epilogue (deep-K GEMMs).  MT minimises the tail of the last round of tiles
+// (M = 16064: 63 x 3 tiles of 256 rows = 0.74 rounds of 256 CUs, 84 x 3 of 192 = 0.98).
+static inline void gam_gemm_sp_pick(int M, int N, int K, int& mt, int& nw, int ncu = 256) {
+  static int f_mt = -1, f_nw = -1;
+  if (f_mt < 0) { const char* e = getenv("GAM_SP_MT"); f_mt = e ? atoi(e) : 0; }
+  if (f_nw < 0) { const char* e = getenv("GAM_SP_NW"); f_nw = e ? atoi(e) : 0; }
+  nw = (f_nw == 2 || f_nw == 4) ? f_nw : (K >= 6144 ? 4 : 2);
+  const int slots = nw == 2 ? 2 * ncu : ncu;
+  const int mt_max = nw == 2 ? 3 : 4;
+  mt = mt_max;
+  double best_cost = 1e30;
+  for (int t = mt_max; t >= 2; --t) {
+    const long tiles = (long)gam_cdiv(M, 64 * t) * gam_cdiv(N, 64 * nw);
+    const double rounds = (double)((tiles + slots - 1) / slots);
+    const double cost = rounds * (t + 0.6);   // MFMA work + a fixed share (W tile, barriers, epilogue)
+    if (cost < best_cost - 1e-9) { best_cost = cost; mt = t; }
+  }
+  if (f_mt >= 2 && f_mt <= mt_max) mt = f_mt;
+}
+
+static inline hipError_t gam_launch_gemm_sp(const GamGemmArgs& a_in, int act, hipStream_t stream) {
+  GamGemmArgs a = a_in;
+  if (a.M <= 0 || a.N <= 0) return hipSuccess;
+  if (a.K <= 0 || a.K % 32 != 0 || a.Asp == nullptr || a.Wsp == nullptr) return hipErrorInvalidValue;
+  if (a.a_mode == 0 ? (a.lda % 32 != 0) : (a.conv_c % 32 != 0)) return hipErrorInvalidValue;
+  if (!gam_gemm_sp_epilogue_ok(a)) return hipErrorInvalidValue;
+  int mt, nw;
+  gam_gemm_sp_pick(a.M, a.N, a.K, mt, nw);
+  const int grid = gam_cdiv(a.M, 64 * mt) * gam_cdiv(a.N, 64 * nw);
+  a.ntiles = grid;
+  static int dbg = -1;
+  if (dbg < 0) { const char* e = getenv("GAM_SP_DBG"); dbg = e ? atoi(e) : 0; }
+  a.dbg = dbg;
+#define GAM_LSP(ACTV)                                                            \
+  if (nw == 2) switch (mt) {                                                     \
+    case 2: gam_launch_gemm_sp_t<ACTV, 2, 2>(a, grid, stream); break;            \
+    default: gam_launch_gemm_sp_t<ACTV, 3, 2>(a, grid, stream); break;           \
+  } else switch (mt) {                                                           \
+    case 2: gam_launch_gemm_sp_t<ACTV, 2, 4>(a, grid, stream); break;            \
+    case 3: gam_launch_gemm_sp_t<ACTV, 3, 4>(a, grid, stream); break;            \
+    default: gam_launch_gemm_sp_t<ACTV, 4, 4>(a, grid, stream); break;           \
+  }
+  switch (act) {
+    case GAM_ACT_SILU: GAM_LSP(GAM_ACT_SILU); break;
+    case GAM_ACT_RELU: GAM_LSP(GAM_ACT_RELU); break;
+    default: GAM_LSP(GAM_ACT_NONE); break;
+  }
+#undef GAM_LSP
+  return hipGetLastError();
+}
+
+// fp32 [rows, K] (row pitch lda elements) -> sp32 (row pitch 2*lda halfs); 4 elements per thread
+__global__ __launch_bounds__(256) void gam_to_sp32_kernel(const float* __restrict__ x, _Float16* __restrict__ y,
+                                                          size_t n4) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    gam_half4 h, l;
+    gam_split4(v, h, l);
+    const size_t e = i * 4;                       // flat element index; 32-element blocks are row-aligned
+    _Float16* p = y + (e >> 5) * 64 + (e & 31);
+    *reinterpret_cast<gam_half4*>(p) = h;
+    *reinterpret_cast<gam_half4*>(p + 32) = l;
+  }
+}

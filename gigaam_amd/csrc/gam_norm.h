@@ -20,6 +20,7 @@ struct GamLnArgs {
   const float* rcos; const float* rsin;  // MODE 1: [Tmax, dk/2]
   int rows, d, ta, dk;
   float eps;
+  int split1, split2;   // write out1 / out2 in the sp32 GEMM-operand layout (gam_common.h)
 };
 
 __device__ __forceinline__ void gam_ln_row(float4 (&v)[GAM_LN_MAXJ], int d, int lane, float eps,
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void gam_layernorm_kernel(GamLnArgs a) {
 #pragma unroll
     for (int j = 0; j < GAM_LN_MAXJ; ++j) {
       const int c = (j * 64 + lane) * 4;
-      if (c < a.d) *reinterpret_cast<float4*>(a.out1 + (size_t)row * a.d + c) = v[j];
+      if (c < a.d) gam_store4(a.out1, (size_t)row * a.d, c, v[j].x, v[j].y, v[j].z, v[j].w, a.split1);
     }
   }
   if (MODE == 2) {
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void gam_layernorm_kernel(GamLnArgs a) {
 #pragma unroll
       for (int j = 0; j < GAM_LN_MAXJ; ++j) {
         const int c = (j * 64 + lane) * 4;
-        if (c < a.d) *reinterpret_cast<float4*>(a.out2 + (size_t)row * a.d + c) = v[j];
+        if (c < a.d) gam_store4(a.out2, (size_t)row * a.d, c, v[j].x, v[j].y, v[j].z, v[j].w, a.split2);
       }
     }
   }
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void gam_layernorm_kernel(GamLnArgs a) {
           else          r = self * cs[i - half] + rb[cc - half] * sn[i - half];
           o[e] = r;
         }
-        if (live) *reinterpret_cast<float4*>(a.out2 + (size_t)row * a.d + c) = make_float4(o[0], o[1], o[2], o[3]);
+        if (live) gam_store4(a.out2, (size_t)row * a.d, c, o[0], o[1], o[2], o[3], a.split2);
       }
     }
   }
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(256) void gam_layernorm_kernel(GamLnArgs a) {
 static inline hipError_t gam_launch_layernorm(const GamLnArgs& a, int mode, hipStream_t s) {
   if (a.rows <= 0) return hipSuccess;
   if (a.d % 4 != 0 || a.d > GAM_LN_MAXJ * 256) return hipErrorInvalidValue;
+  if ((a.split1 || a.split2) && a.d % 32 != 0) return hipErrorInvalidValue;
   const int grid = gam_cdiv(a.rows, 4);
   if (mode == 0) hipLaunchKernelGGL(gam_layernorm_kernel<0>, dim3(grid), dim3(256), 0, s, a);
   else if (mode == 1) hipLaunchKernelGGL(gam_layernorm_kernel<1>, dim3(grid), dim3(256), 0, s, a);

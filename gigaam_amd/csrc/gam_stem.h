@@ -40,6 +40,7 @@ struct GamConv1Args {
   const int* len0;     // valid input frames
   const int* len1;     // valid output frames of this stage
   int B, T, F, Ta, FP, C, T1;
+  int img_split;       // channels of a pixel in the sp32 GEMM-operand layout (C % 32 == 0)
 };
 
 __global__ __launch_bounds__(256) void gam_conv2d1_kernel(GamConv1Args a) {
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void gam_conv2d1_kernel(GamConv1Args a) {
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) acc = fmaf(w[kh * 3 + kw], xin[kh][fb + kw], acc);
-      out[(size_t)q * a.C + c] = fmaxf(acc, 0.f);
+      gam_store1(out, (size_t)q * a.C, c, fmaxf(acc, 0.f), a.img_split);
     }
   }
 }

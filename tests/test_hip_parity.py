@@ -13,25 +13,41 @@ pytestmark = pytest.mark.gpu
 SUPPORTED = list(CASES)
 
 
-MODES = ["f16x3", "f32"]   # both arithmetic modes of the dense contractions must hold the same bars
+# every arithmetic mode of the dense contractions must hold the same bars.  "f16x3-sp" is f16x3 with
+# the large-batch path (LDS-DMA GEMM on sp32 operands written by the producing kernels, gam_gemm_sp.h)
+# forced on at these small sizes; by default it engages from 2048 token rows.
+MODES = ["f16x3", "f16x3-sp", "f32"]
+
+
+def _make_engine(cfg, state_dict, mode, head=True):
+    import os
+    from gigaam_amd.engine import HipEngine, build_config
+    sp = mode.endswith("-sp")
+    old = os.environ.get("GAM_SP_MIN_M")
+    if sp:
+        os.environ["GAM_SP_MIN_M"] = "1"   # read when the handle is created
+    try:
+        eng = HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], cfg.get("head") if head else None), state_dict,
+                        torch.device("cuda:0"))
+    finally:
+        if sp:
+            if old is None:
+                del os.environ["GAM_SP_MIN_M"]
+            else:
+                os.environ["GAM_SP_MIN_M"] = old
+    eng.set_gemm_mode(mode.split("-")[0])
+    assert eng.gemm_mode == mode.split("-")[0]
+    return eng
 
 
 def _engine(ck, mode="f16x3"):
-    from gigaam_amd.engine import HipEngine, build_config
-    cfg = ck["cfg"]
-    eng = HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], cfg.get("head")), ck["state_dict"], torch.device("cuda:0"))
-    eng.set_gemm_mode(mode)
-    assert eng.gemm_mode == mode
-    return eng
+    return _make_engine(ck["cfg"], ck["state_dict"], mode)
 
 
 @pytest.mark.parametrize("mode", MODES)
 def test_gemm_kernel_shapes_and_epilogues(mode):
     from gigaam_amd import synth
-    from gigaam_amd.engine import HipEngine, build_config
-    cfg = synth.model_cfg("v2_ctc")
-    eng = HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], None), {}, torch.device("cuda:0"))
-    eng.set_gemm_mode(mode)
+    eng = _make_engine(synth.model_cfg("v2_ctc"), {}, mode, head=False)
     g = torch.Generator().manual_seed(0)
     # asymmetric operands, ragged M/N edges, all activations (transposes / layout slips cannot hide)
     # the last three shapes reach the many-tile variants (128x128 phase-separated, 256x128)
@@ -57,10 +73,7 @@ def test_gemm_kernel_shapes_and_epilogues(mode):
 def test_attention_kernel(mode):
     """Fused attention kernel alone against an fp64 softmax(QK^T/sqrt(dk))V with key masking."""
     from gigaam_amd import synth
-    from gigaam_amd.engine import HipEngine, build_config
-    cfg = synth.model_cfg("v2_ctc")
-    eng = HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], None), {}, torch.device("cuda:0"))
-    eng.set_gemm_mode(mode)
+    eng = _make_engine(synth.model_cfg("v2_ctc"), {}, mode, head=False)
     g = torch.Generator().manual_seed(3)
     for (b, t, h, lens) in [(1, 16, 1, None), (2, 70, 2, [70, 33]), (3, 203, 16, [203, 150, 1])]:
         q, k, v = (torch.randn(b, t, h * 48, generator=g) * s for s in (2.0, 2.0, 1.0))
