@@ -215,7 +215,8 @@ def main():
             kern, peak, issued = "gam_gemm_f32_kernel (v_mfma_f32_32x32x2_f32; plain + implicit-GEMM conv)", FP32_MFMA_PEAK_TFLOPS, ach
         else:
             # every algorithmic FLOP costs three fp16 MFMA FLOPs (hi.hi + hi.lo + lo.hi)
-            kern, peak, issued = "gam_gemm_f16x3_kernel (3x v_mfma_f32_32x32x16_f16 per product; plain + implicit-GEMM conv)", F16_MFMA_PEAK_TFLOPS, 3.0 * ach
+            kern, peak, issued = ("gam_gemm_sp_kernel (LDS-DMA, sp32 operands; small GEMMs: gam_gemm_f16x3_kernel) -- 3x "
+                                  "v_mfma_f32_32x32x16_f16 per product; plain + implicit-GEMM conv"), F16_MFMA_PEAK_TFLOPS, 3.0 * ach
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.gemm}.json")
         if args.model == "v2_ctc" and args.batch == 32 and args.seconds == 20.0 and os.path.exists(tpath):

@@ -26,6 +26,14 @@
 #pragma once
 #include "gam_gemm16.h"
 
+// -DGAM_SP_INSTRUMENT=1 compiles the GAM_SP_DBG experiment switches in (1: skip the epilogue, 2: one
+// k-tile only, 4: per-phase clock64 counters written into the last C row, 8: drop the in-loop barrier).
+// They produced profiles/r01_gemm_sp_clock_random_vs_zero.txt; production builds carry none of it.
+#ifndef GAM_SP_INSTRUMENT
+#define GAM_SP_INSTRUMENT 0
+#endif
+#define GAM_SP_DBG(g) (GAM_SP_INSTRUMENT ? (g).dbg : 0)
+
 #define GAM_SP_MIN_M 2048   // below this the 128x128 kernels fill the chip better
 
 // compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
   // Everything that is not an MFMA is issued one or two items at a time BETWEEN MFMAs: an LDS-DMA piece
   // costs the issuing wave ~60+ cycles, and with the whole refill issued in one block after the barrier
   // both waves of a SIMD sat in it together and the matrix pipe idled ~600 of every 3500 cycles
-  // (clock64 instrumentation, GAM_SP_DBG=4).  Fragment reads get >= 2/3 of a phase to land.
+  // (clock64 instrumentation, GAM_SP_INSTRUMENT build with GAM_SP_DBG=4).  Fragment reads get >= 2/3 of a phase to land.
   gam_half8 fah[2][MT], fal[2][MT], fbh[2][2], fbl[2][2];
   constexpr int NM = 6 * MT;        // MFMAs per phase: 3 terms x MT x 2 tiles
   constexpr int NR = 2 * MT + 4;    // fragment reads per set
@@ -251,34 +259,34 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
   using F_ = std::integral_constant<bool, false>;
 
   long long t_bar = 0, t_mm0 = 0, t_mm1 = 0, t_start = 0, w_start = 0;
-  if (g.dbg & 4) { t_start = clock64(); w_start = wall_clock64(); }
+  if (GAM_SP_DBG(g) & 4) { t_start = clock64(); w_start = wall_clock64(); }
   issue(0);
   issue(1);   // (nk == 1: fetches tile 0 again, unused)
   __builtin_amdgcn_s_waitcnt(0x0070);
   __syncthreads();   // both tiles have landed for every wave
 #pragma unroll
   for (int q = 0; q < NR; ++q) GAM_SP_RDITEM(0, q, gam_smem_sp, o_h0, o_l0);
-  const int nk_run = (g.dbg & 2) ? 1 : nk;
+  const int nk_run = (GAM_SP_DBG(g) & 2) ? 1 : nk;
   for (int kt = 0; kt < nk_run; ++kt) {
     const unsigned char* st = gam_smem_sp + (kt & 1) * Cfg::STAGE;
     const unsigned char* sn = gam_smem_sp + ((kt & 1) ^ 1) * Cfg::STAGE;
     long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-    if (g.dbg & 4) c0 = clock64();
+    if (GAM_SP_DBG(g) & 4) c0 = clock64();
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): set 0 landed (read >= 2/3 of a phase ago)
     phase(C0_{}, F_{}, st, o_h1, o_l1, 0);
-    if (g.dbg & 4) c1 = clock64();
+    if (GAM_SP_DBG(g) & 4) c1 = clock64();
     // vmcnt(0) by hand: this wave's DMA pieces of tile kt+1 have landed (hipcc does not reliably order
     // an LDS-DMA against the ds_reads behind a later barrier); lgkmcnt(0): set 1 is in registers
     __builtin_amdgcn_s_waitcnt(0x0070);
-    __syncthreads();
-    if (g.dbg & 4) c2 = clock64();
+    if (!(GAM_SP_DBG(g) & 8)) __syncthreads();
+    if (GAM_SP_DBG(g) & 4) c2 = clock64();
     // Unconditional (one copy of the MFMA stream; a second, DMA-less copy behind a branch made hipcc
     // double-buffer the accumulators): past the end the set-0 reads fetch stale LDS that is never used
     // and the DMA re-fetches the last k-tile into a stage nobody reads again (drained before the epilogue).
     phase(C1_{}, T_{}, sn, o_h0, o_l0, kt & 1);
-    if (g.dbg & 4) { c3 = clock64(); t_mm0 += c1 - c0; t_bar += c2 - c1; t_mm1 += c3 - c2; }
+    if (GAM_SP_DBG(g) & 4) { c3 = clock64(); t_mm0 += c1 - c0; t_bar += c2 - c1; t_mm1 += c3 - c2; }
   }
-  if ((g.dbg & 4) && lane == 0 && (lid == 0 || lid == gridDim.x - 1)) {
+  if ((GAM_SP_DBG(g) & 4) && lane == 0 && (lid == 0 || lid == gridDim.x - 1)) {
     // [total clk, total wall(100 MHz), phase 0, barrier, phase 1] of one wave
     float* d = g.C + (size_t)(g.M - 1) * g.ldc + (lid == 0 ? 0 : 64) + wave * 8;
     d[0] = (float)(clock64() - t_start); d[1] = (float)(wall_clock64() - w_start);
@@ -293,7 +301,7 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
   __syncthreads();
 
   const int mw = m0 + wm * (BM / 2), nw = n0 + wn * 64;
-  if ((g.dbg & 1) && acc[0][0][0] != 123.456f) return;
+  if ((GAM_SP_DBG(g) & 1) && acc[0][0][0] != 123.456f) return;
 
   // ---- epilogue.  Each wave transposes its 32 x 64 slabs through a private LDS scratch (the stages
   //      are dead: the last reads completed before the final barrier, no DMA is outstanding) so that
@@ -368,27 +376,29 @@ static inline void gam_launch_gemm_sp_t(const GamGemmArgs& a, int grid, hipStrea
   hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * NW), smem, stream, a);
 }
 
-// Tile shape.  NW = 2: (64 MT) x 128 tiles, 4 waves, 2 workgroups per CU (80 KB LDS each at MT = 3):
-// the two run out of phase, so one's epilogue / barrier waits hide under the other's MFMAs.
-// NW = 4: (64 MT) x 256 tiles, 8 waves, 1 workgroup per CU: fewest bytes per FLOP, nothing hides
-// the epilogue (deep-K GEMMs).  MT minimises the tail of the last round of tiles
-// (M = 16064: 63 x 3 tiles of 256 rows = 0.74 rounds of 256 CUs, 84 x 3 of 192 = 0.98).
+// Tile shape.  NW = 4: (64 MT) x 256 tiles, 8 waves, one workgroup per CU -- fewest bytes per FLOP.
+// NW = 2: (64 MT) x 128 tiles, 4 waves, two workgroups per CU -- twice the tiles, for grids that
+// would leave CUs idle.  Cost model (units: MFMA work of a 64 x 256 strip): the busiest CU runs
+// ceil(tiles / CUs) tiles of MT * NW/4 units plus a fixed share per tile (prologue, epilogue);
+// measured at M = 16064 / 4016 it ranks the six shapes the way the sweep did
+// (e.g. N = 768: 84 x 3 tiles of 192 x 256 = 0.98 rounds beat 63 x 3 of 256 x 256 = 0.74).
 static inline void gam_gemm_sp_pick(int M, int N, int K, int& mt, int& nw, int ncu = 256) {
   static int f_mt = -1, f_nw = -1;
   if (f_mt < 0) { const char* e = getenv("GAM_SP_MT"); f_mt = e ? atoi(e) : 0; }
   if (f_nw < 0) { const char* e = getenv("GAM_SP_NW"); f_nw = e ? atoi(e) : 0; }
-  nw = (f_nw == 2 || f_nw == 4) ? f_nw : (K >= 6144 ? 4 : 2);
-  const int slots = nw == 2 ? 2 * ncu : ncu;
-  const int mt_max = nw == 2 ? 3 : 4;
-  mt = mt_max;
-  double best_cost = 1e30;
-  for (int t = mt_max; t >= 2; --t) {
-    const long tiles = (long)gam_cdiv(M, 64 * t) * gam_cdiv(N, 64 * nw);
-    const double rounds = (double)((tiles + slots - 1) / slots);
-    const double cost = rounds * (t + 0.6);   // MFMA work + a fixed share (W tile, barriers, epilogue)
-    if (cost < best_cost - 1e-9) { best_cost = cost; mt = t; }
+  (void)K;
+  double best = 1e30;
+  mt = 3; nw = 4;
+  for (int w = 4; w >= 2; w -= 2) {
+    if ((f_nw == 2 || f_nw == 4) && w != f_nw) continue;
+    for (int t = (w == 2 ? 3 : 4); t >= 2; --t) {
+      if (f_mt >= 2 && f_mt <= 4 && t != f_mt && !(w == 2 && f_mt == 4)) continue;
+      const long tiles = (long)gam_cdiv(M, 64 * t) * gam_cdiv(N, 64 * w);
+      const double per_cu = (double)((tiles + ncu - 1) / ncu);
+      const double cost = per_cu * (t * (w / 4.0) + (w == 4 ? 0.6 : 0.45));
+      if (cost < best - 1e-9) { best = cost; mt = t; nw = w; }
+    }
   }
-  if (f_mt >= 2 && f_mt <= mt_max) mt = f_mt;
 }
 
 static inline hipError_t gam_launch_gemm_sp(const GamGemmArgs& a_in, int act, hipStream_t stream) {

@@ -32,6 +32,8 @@ def main():
     for (m, n, k, act) in shapes:
         a = torch.randn(m, k, device="cuda")
         w = torch.randn(n, k, device="cuda") / k ** 0.5
+        if os.environ.get("GAM_TEST_ZEROS"):      # data-dependent power: same kernel, all-zero operands
+            a.zero_(); w.zero_()
         b = torch.randn(n, device="cuda")
         ref = a.double() @ w.double().t() + b.double()
         if act == 1:
