@@ -98,7 +98,8 @@ struct gam_handle {
   int presplit = 0;   // GAM_PRESPLIT=1: split A in a pre-pass (experiment)
   int use_sp = 1;     // large-M GEMMs on the LDS-DMA sp32 kernel (GAM_SP=0 disables)
   int sp_min_m = GAM_SP_MIN_M;   // GAM_SP_MIN_M overrides (tests force the sp path at small sizes)
-  DevBuf op_planes, op_sp; const float* op_w = nullptr; size_t op_count = 0;   // gam_op_gemm W-plane cache
+  DevBuf op_planes, op_sp, splitk_ws; const float* op_w = nullptr; size_t op_count = 0;   // gam_op_gemm W-plane cache
+  int use_splitk = 1;   // GAM_SPLITK=0 disables split-K for small grids const float* op_w = nullptr; size_t op_count = 0;   // gam_op_gemm W-plane cache
   int* lens = nullptr;  // 4 * maxB ints: len0, len1, len2, enc_len
   int lens_cap = 0;
 
@@ -271,16 +272,35 @@ int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls
     h->prof_bytes[cls] += abytes + 4.0 * a.N * a.K + 4.0 * a.M * a.N * (a.R ? 2.0 : 1.0);
   }
   hipError_t e;
-  if (h->gemm_mode == 1 && w16 != nullptr && w16->hi != nullptr) {
+  const bool f16 = h->gemm_mode == 1 && w16 != nullptr && w16->hi != nullptr;
+  if (f16 && a.Asp != nullptr) {
+    if (w16->sp == nullptr) return fail(h, -2, "sp32 A without sp32 W planes");
     a.Whi = w16->hi; a.Wlo = w16->lo; a.wscale_inv = w16->inv;
-    if (a.Asp != nullptr) {
-      if (w16->sp == nullptr) return fail(h, -2, "sp32 A without sp32 W planes");
-      a.Wsp = w16->sp;
-      e = gam_launch_gemm_sp(a, act, s);
-      if (e != hipSuccess) return fail(h, -2, "sp gemm launch (M=%d N=%d K=%d): %s", a.M, a.N, a.K, hipGetErrorString(e));
-      return 0;
+    a.Wsp = w16->sp;
+    e = gam_launch_gemm_sp(a, act, s);
+    if (e != hipSuccess) return fail(h, -2, "sp gemm launch (M=%d N=%d K=%d): %s", a.M, a.N, a.K, hipGetErrorString(e));
+    return 0;
+  }
+  if (a.Asp != nullptr) return fail(h, -2, "sp32 A operand outside the split-fp16 GEMM mode");
+  // Split-K for grids that would leave most CUs idle (single clips, short batches: 126 tokens x 768
+  // columns = 6 tiles): S slices of K write partial sums, a second pass sums them in a fixed order
+  // (bit-reproducible) and applies the epilogue.
+  int S = 1;
+  if (h->use_splitk && a.a_mode == 0 && a.K % 32 == 0) {
+    const int tiles = gam_cdiv(a.M, 128) * gam_cdiv(a.N, 128), nk = a.K / 32, ncu = 256;
+    if (tiles * 2 <= ncu && nk >= 4) {
+      S = std::min(16, std::min(ncu / tiles, nk / 2));
+      while (S > 1 && nk % S != 0) --S;
     }
-    if (h->presplit && a.Ahi == nullptr && a.a_mode == 0) {
+  }
+  GamGemmArgs full = a;
+  if (S > 1) {
+    if (int r = ensure(h, h->splitk_ws, (size_t)S * a.M * a.N + 64)) return r;
+    a.splitk = S; a.ldw = a.K; a.K = a.K / S; a.partial = h->splitk_ws.p;
+  }
+  if (f16) {
+    a.Whi = w16->hi; a.Wlo = w16->lo; a.wscale_inv = w16->inv;
+    if (h->presplit && S == 1 && a.Ahi == nullptr && a.a_mode == 0) {
       const size_t count = ((size_t)(a.M - 1) * (size_t)a.lda + (size_t)a.K + 7) / 8 * 8;
       if (int r = ensure(h, h->aplanes, count + 64)) return r;
       _Float16* hi = (_Float16*)h->aplanes.p;
@@ -295,6 +315,11 @@ int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls
     e = gam_launch_gemm(a, act, s);
   }
   if (e != hipSuccess) return fail(h, -2, "gemm launch (M=%d N=%d K=%d): %s", a.M, a.N, a.K, hipGetErrorString(e));
+  if (S > 1) {
+    full.partial = a.partial;
+    e = gam_launch_splitk_reduce(full, act, S, s);
+    if (e != hipSuccess) return fail(h, -2, "split-K reduce launch (M=%d N=%d): %s", a.M, a.N, hipGetErrorString(e));
+  }
   return 0;
 }
 
@@ -335,6 +360,7 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   if (const char* e = getenv("GAM_PRESPLIT")) h->presplit = atoi(e);
   if (const char* e = getenv("GAM_SP")) h->use_sp = atoi(e);
   if (const char* e = getenv("GAM_SP_MIN_M")) h->sp_min_m = atoi(e);
+  if (const char* e = getenv("GAM_SPLITK")) h->use_splitk = atoi(e);
   if (const char* e = getenv("GAM_GEMM_MODE")) h->gemm_mode = (strcmp(e, "f32") == 0) ? GAM_GEMM_F32 : GAM_GEMM_F16X3;
   const gam_config& c = h->cfg;
   if (c.d_model <= 0 || c.n_heads <= 0 || c.d_model % c.n_heads != 0)
@@ -357,7 +383,7 @@ void gam_destroy(gam_handle* h) {
   hipSetDevice(h->device);
   for (void* p : h->owned) hipFree(p);
   DevBuf* bufs[] = {&h->wavp, &h->spec, &h->img, &h->c2, &h->xin, &h->y1, &h->x, &h->y, &h->yr, &h->hbuf,
-                    &h->qk, &h->vbuf, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes};
+                    &h->qk, &h->vbuf, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes, &h->op_sp, &h->splitk_ws};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   if (h->lens) hipFree(h->lens);

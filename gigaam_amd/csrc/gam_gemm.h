@@ -61,6 +61,12 @@ struct GamGemmArgs {
   const _Float16* Asp;
   const _Float16* Wsp;
   int c_split;          // write C in the sp32 layout (row pitch ldc elements) instead of fp32
+  // split-K (small grids): grid.y = splitk slices of K; this struct's K is the slice length, ldw the
+  // full row pitch of W; slice s reads columns [s*K, (s+1)*K) and writes its raw partial sums to
+  // partial[s][M][N]; gam_splitk_reduce_kernel applies the epilogue.  0 / 1 = off.
+  int splitk;
+  long ldw;             // row pitch of W / Whi / Wlo in elements (0 = K)
+  float* partial;
   int ntiles;           // set by the launcher
   int dbg;              // experiment switches (GAM_SP_DBG), 0 in production
   float wscale_inv;     // 2^-wshift, applied to the accumulator in the epilogue
@@ -79,6 +85,23 @@ __device__ __forceinline__ void gam_gemm_epilogue(const GamGemmArgs& g, const f3
                                                   int wn, int lane, float accscale) {
   const int lcol = lane & 31;
   const int lrow4 = 4 * (lane >> 5);
+  if (g.partial != nullptr) {   // split-K slice: raw partial sums, the reduce kernel finishes
+    float* P = g.partial + (size_t)blockIdx.y * (size_t)g.M * (size_t)g.N;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
+        if (row >= g.M) continue;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          const int col = n0 + wn * 64 + tn * 32 + lcol;
+          if (col < g.N)
+            P[(size_t)row * g.N + col] = (tm == 0 ? (tn == 0 ? acc00[r] : acc01[r]) : (tn == 0 ? acc10[r] : acc11[r])) * accscale;
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
 #pragma unroll
@@ -115,6 +138,7 @@ __device__ __forceinline__ void gam_gemm_epilogue(const GamGemmArgs& g, const f3
 template <int ACT, int NBUF>
 __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gam_gemm_f32_kernel(GamGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) float gam_smem[];
+  if (g.splitk > 1) { const size_t ko = (size_t)blockIdx.y * (size_t)g.K; g.A += ko; g.W += ko; }
   constexpr int BM = GAM_GEMM_BM, BN = GAM_GEMM_BN, BK = GAM_GEMM_BK, LD = GAM_GEMM_LD;
   float* As = gam_smem;
   float* Bs = gam_smem + NBUF * BM * LD;
@@ -148,7 +172,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gam_gemm_f32_kernel(Ga
   auto w_row_off = [&](int i) -> size_t {
     int n = n0 + lrow + 32 * i;
     n = n < g.N ? n : g.N - 1;
-    return (size_t)n * (size_t)g.K;
+    return (size_t)n * (size_t)g.ldw;
   };
   const float* pa0 = g.A + a_row_off(0) + lc4;
   const float* pa1 = g.A + a_row_off(1) + lc4;
@@ -265,7 +289,7 @@ static inline void gam_launch_gemm_t(const GamGemmArgs& a, int grid, hipStream_t
                               hipFuncAttributeMaxDynamicSharedMemorySize, GAM_GEMM_SMEM(NBUF));
     attr_done = true;
   }
-  hipLaunchKernelGGL((gam_gemm_f32_kernel<ACT, NBUF>), dim3(grid), dim3(256), GAM_GEMM_SMEM(NBUF), stream, a);
+  hipLaunchKernelGGL((gam_gemm_f32_kernel<ACT, NBUF>), dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(256), GAM_GEMM_SMEM(NBUF), stream, a);
 }
 
 // GAM_GEMM_NBUF=2 selects the double-buffered variant (A/B measurements only)
@@ -278,7 +302,9 @@ static inline int gam_gemm_nbuf() {
   return v;
 }
 
-static inline hipError_t gam_launch_gemm(const GamGemmArgs& a, int act, hipStream_t stream) {
+static inline hipError_t gam_launch_gemm(const GamGemmArgs& a_in, int act, hipStream_t stream) {
+  GamGemmArgs a = a_in;
+  if (a.ldw == 0) a.ldw = a.K;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K % GAM_GEMM_BK != 0 || a.K <= 0) return hipErrorInvalidValue;
   const int grid = gam_cdiv(a.M, GAM_GEMM_BM) * gam_cdiv(a.N, GAM_GEMM_BN);
@@ -294,5 +320,74 @@ static inline hipError_t gam_launch_gemm(const GamGemmArgs& a, int act, hipStrea
       if (one) gam_launch_gemm_t<GAM_ACT_NONE, 1>(a, grid, stream); else gam_launch_gemm_t<GAM_ACT_NONE, 2>(a, grid, stream);
       break;
   }
+  return hipGetLastError();
+}
+
+// ---- split-K second pass: C = epilogue(sum_s partial[s]) with the same epilogue semantics as above.
+//      One thread per 4 consecutive columns (N % 4 == 0) or per column.
+template <int ACT, int VEC>
+__global__ __launch_bounds__(256) void gam_splitk_reduce_kernel(GamGemmArgs g, int S) {
+  const int cpr = (g.N + VEC - 1) / VEC;                       // column groups per row
+  const size_t total = (size_t)g.M * cpr;
+  const size_t slice = (size_t)g.M * (size_t)g.N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int row = (int)(i / cpr), col = (int)(i % cpr) * VEC;
+    float v[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = 0.f;
+    const float* p = g.partial + (size_t)row * g.N + col;
+    for (int s = 0; s < S; ++s) {
+      if (VEC == 4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(p + s * slice);
+        v[0] += t.x; v[1 % VEC] += t.y; v[2 % VEC] += t.z; v[3 % VEC] += t.w;
+      } else {
+        v[0] += p[s * slice];
+      }
+    }
+    bool masked = false;
+    long orow = row;
+    if (g.lens != nullptr || g.remap) {
+      const int bb = row / g.rpb, tt = row - bb * g.rpb;
+      if (g.lens != nullptr) masked = (tt / g.fdiv) >= g.lens[bb];
+      if (g.remap) {
+        if (tt >= g.rows_valid) continue;
+        orow = (long)bb * g.out_rpb + tt + g.out_shift;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float x = v[e];
+      if (g.bias != nullptr) x += g.bias[col + e];
+      if (ACT == GAM_ACT_SILU) x = gam_silu(x);
+      if (ACT == GAM_ACT_RELU) x = fmaxf(x, 0.0f);
+      if (masked) x = 0.0f;
+      x *= g.alpha;
+      if (g.R != nullptr) x += g.R[orow * g.ldr + col + e];
+      v[e] = x;
+    }
+    if (VEC == 4) {
+      if (g.c_split) gam_store4(g.C, (size_t)orow * g.ldc, col, v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC], 1);
+      else *reinterpret_cast<f32x4*>(g.C + orow * g.ldc + col) = (f32x4){v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]};
+    } else {
+      gam_store1(g.C, (size_t)orow * g.ldc, col, v[0], g.c_split);
+    }
+  }
+}
+
+static inline hipError_t gam_launch_splitk_reduce(const GamGemmArgs& a, int act, int S, hipStream_t stream) {
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  const bool vec = a.N % 4 == 0 && a.ldc % 4 == 0 && al16(a.C) && al16(a.partial) &&
+                   (a.R == nullptr || (a.ldr % 4 == 0 && al16(a.R)));
+  const size_t total = (size_t)a.M * (vec ? a.N / 4 : a.N);
+  const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+#define GAM_RED(ACTV)                                                                                      \
+  if (vec) hipLaunchKernelGGL((gam_splitk_reduce_kernel<ACTV, 4>), dim3(grid), dim3(256), 0, stream, a, S); \
+  else hipLaunchKernelGGL((gam_splitk_reduce_kernel<ACTV, 1>), dim3(grid), dim3(256), 0, stream, a, S);
+  switch (act) {
+    case GAM_ACT_SILU: GAM_RED(GAM_ACT_SILU); break;
+    case GAM_ACT_RELU: GAM_RED(GAM_ACT_RELU); break;
+    default: GAM_RED(GAM_ACT_NONE); break;
+  }
+#undef GAM_RED
   return hipGetLastError();
 }

@@ -38,6 +38,11 @@ struct GamGemm16Cfg {
 template <int ACT, int BK, bool AP, int BM, bool PIPE>
 __global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : (BK == 32 ? 3 : 2))) void gam_gemm_f16x3_kernel(GamGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) _Float16 gam_smem16[];
+  if (g.splitk > 1) {
+    const size_t ko = (size_t)blockIdx.y * (size_t)g.K;
+    g.A += ko; g.Whi += ko; g.Wlo += ko;
+    if constexpr (AP) { g.Ahi += ko; g.Alo += ko; }
+  }
   using Cfg = GamGemm16Cfg<BK, BM>;
   constexpr int BN = 128, LD = Cfg::LD, NT = Cfg::NT;
   _Float16* Ahi = gam_smem16;
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : (BK == 32 ? 3 :
     const int row = c / CHR, part = (c % CHR) * 8;
     int n = n0 + row;
     n = n < g.N ? n : g.N - 1;
-    w_off[i] = (size_t)n * (size_t)g.K + part;
+    w_off[i] = (size_t)n * (size_t)g.ldw + part;
     w_lds[i] = row * LD + part;
   }
 
@@ -268,7 +273,7 @@ static inline void gam_launch_gemm16_t(const GamGemmArgs& a, int grid, hipStream
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(2 * BM), smem, stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(2 * BM), smem, stream, a);
 }
 
 // fp32 -> (hi, lo) fp16 planes over a flat range (elementwise, HBM-bound: 4 B in, 4 B out)
@@ -295,6 +300,7 @@ static inline int gam_gemm16_bk() {
 
 static inline hipError_t gam_launch_gemm16(const GamGemmArgs& a_in, int act, hipStream_t stream) {
   GamGemmArgs a = a_in;
+  if (a.ldw == 0) a.ldw = a.K;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K <= 0 || a.Whi == nullptr || a.Wlo == nullptr) return hipErrorInvalidValue;
   // 256x128 tiles (8 waves) move 0.75x the bytes per FLOP of 128x128 ones; used when the grid is
