@@ -14,10 +14,10 @@ from typing import Any, Optional, Union
 
 import torch
 
-from .model import GigaAM, GigaAMASR
+from .model import GigaAM, GigaAMASR, GigaAMEmo
 from .preprocess import load_audio
 
-__all__ = ["GigaAM", "GigaAMASR", "load_audio", "format_time", "load_model", "model_from_checkpoint"]
+__all__ = ["GigaAM", "GigaAMASR", "GigaAMEmo", "load_audio", "format_time", "load_model", "model_from_checkpoint"]
 
 _CACHE_DIR = os.path.expanduser("~/.cache/gigaam")
 # md5 of the reference's published checkpoints (gigaam/__init__.py:28-41)
@@ -55,14 +55,17 @@ def _normalize_device(device: Optional[Union[str, torch.device]]) -> torch.devic
     return torch.device(device) if isinstance(device, str) else device
 
 
-def model_from_checkpoint(checkpoint: dict, device: Optional[Union[str, torch.device]] = None) -> Union[GigaAM, GigaAMASR]:
+def model_from_checkpoint(checkpoint: dict, device: Optional[Union[str, torch.device]] = None) -> Union[GigaAM, GigaAMASR, GigaAMEmo]:
     """Build a model from an in-memory ``{"cfg", "state_dict"}`` checkpoint (the layout
     of the reference's .ckpt files, gigaam/__init__.py:167-185)."""
     cfg = checkpoint["cfg"]
     name = cfg["model_name"] if isinstance(cfg, dict) else cfg.model_name
-    if "emo" in str(name):
-        raise ValueError("the emotion head is outside the MI355X hot path (SURVEY.md §8f.4)")
-    model = GigaAM(cfg) if "ssl" in str(name) else GigaAMASR(cfg)
+    if "ssl" in str(name):
+        model = GigaAM(cfg)
+    elif "emo" in str(name):   # gigaam/__init__.py:178-183
+        model = GigaAMEmo(cfg)
+    else:
+        model = GigaAMASR(cfg)
     model.load_state_dict(checkpoint["state_dict"])
     model = model.eval()
     return model.to(_normalize_device(device))
@@ -70,7 +73,7 @@ def model_from_checkpoint(checkpoint: dict, device: Optional[Union[str, torch.de
 
 def load_model(model_name: str, fp16_encoder: bool = True, use_flash: Optional[bool] = False,
                device: Optional[Union[str, torch.device]] = None,
-               download_root: Optional[str] = None) -> Union[GigaAM, GigaAMASR]:
+               download_root: Optional[str] = None) -> Union[GigaAM, GigaAMASR, GigaAMEmo]:
     """Same signature as the reference's ``load_model`` (gigaam/__init__.py:110-192).
 
     ``model_name`` is a model name (checkpoint expected at

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, LIB_NAME)
 SUBS_CONV2D, SUBS_CONV1D = 0, 1
 ATT_ROTARY, ATT_REL_POS = 0, 1
 NORM_BATCH, NORM_LAYER = 0, 1
-HEAD_NONE, HEAD_CTC, HEAD_RNNT = 0, 1, 2
+HEAD_NONE, HEAD_CTC, HEAD_RNNT, HEAD_EMO = 0, 1, 2, 3
 DTYPE_F32, DTYPE_F16, DTYPE_BF16, DTYPE_F64, DTYPE_I64 = 0, 1, 2, 3, 4
 GEMM_F32, GEMM_F16X3 = 0, 1
 PF_CLASSES = ["gemm", "conv2", "attn", "norm", "convmod", "stem", "frontend", "decode", "misc"]
@@ -50,6 +50,7 @@ SIGNATURES = {
     "gam_ctc_head": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P]),
     "gam_ctc_greedy": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P, _P]),
     "gam_rnnt_greedy": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "gam_emo_probs": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P]),
     "gam_set_gemm_mode": (C.c_int, [_P, C.c_int]),
     "gam_get_gemm_mode": (C.c_int, [_P]),
     "gam_op_gemm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

@@ -90,6 +90,7 @@ struct gam_handle {
   float* rel_pe = nullptr;  // rel_pos: sinusoid table, row r + (max_len-1) <-> relative position r
   // heads
   float *ctc_w = nullptr, *ctc_b = nullptr;
+  float *emo_w = nullptr, *emo_b = nullptr;
   float *jn_enc_w = nullptr, *jn_enc_b = nullptr, *jn_pred_t = nullptr, *jn_pred_b = nullptr;
   float *jn_out_w = nullptr, *jn_out_b = nullptr, *lstm_whh_t = nullptr, *lstm_tab = nullptr;
 
@@ -648,7 +649,8 @@ int gam_finalize(gam_handle* h) {
   h->has_encoder = build_encoder;
 
   // ---------------- heads ----------------
-  const bool build_head = find(h, "head.decoder_layers.0.weight") != nullptr || find(h, "head.joint.enc.weight") != nullptr;
+  const bool build_head = find(h, "head.decoder_layers.0.weight") != nullptr || find(h, "head.joint.enc.weight") != nullptr ||
+                          (c.head_type == GAM_HEAD_EMO && find(h, "head.weight") != nullptr);
   h->has_head = build_head;
   if (!build_head) {
   } else if (c.head_type == GAM_HEAD_CTC) {
@@ -656,6 +658,11 @@ int gam_finalize(gam_handle* h) {
     NEED(b, "head.decoder_layers.0.bias", c.num_classes);
     UP(h->ctc_w, w->data);
     UP(h->ctc_b, b->data);
+  } else if (c.head_type == GAM_HEAD_EMO) {
+    NEED(w, "head.weight", (int64_t)c.num_classes * D);
+    NEED(b, "head.bias", c.num_classes);
+    UP(h->emo_w, w->data);
+    UP(h->emo_b, b->data);
   } else if (c.head_type == GAM_HEAD_RNNT) {
     const int V = c.num_classes, PH = c.pred_hidden, JH = c.joint_hidden;
     NEED(emb, "head.decoder.embed.weight", (int64_t)V * PH);
@@ -1061,6 +1068,21 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
   if (sm > 160 * 1024) return fail(h, -1, "RNN-T head too large for the greedy kernel's LDS window");
   if (4 * a.H <= 256 * 5) hipLaunchKernelGGL(gam_rnnt_greedy_kernel<5>, dim3(B), dim3(256), sm, s, a);
   else hipLaunchKernelGGL(gam_rnnt_greedy_kernel<8>, dim3(B), dim3(256), sm, s, a);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int gam_emo_probs(gam_handle* h, const float* encoded, const int32_t* enc_len, int B, int64_t Tp, float* probs,
+                  void* stream) {
+  if (!h) return -1;
+  if (h->cfg.head_type != GAM_HEAD_EMO || !h->has_head) return fail(h, -1, "model has no emotion head");
+  if (B <= 0 || Tp <= 0 || !encoded || !probs) return fail(h, -1, "bad emotion-head arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int D = h->cfg.d_model, NC = h->cfg.num_classes;
+  ProfScope ps(h, s, GAM_PF_DECODE, (double)B * D * Tp * 4.0);
+  hipLaunchKernelGGL(gam_emo_head_kernel, dim3(B), dim3(256), (size_t)(D + NC) * sizeof(float), s, encoded, enc_len,
+                     h->emo_w, h->emo_b, probs, D, (int)Tp, NC);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

@@ -332,3 +332,45 @@ __global__ __launch_bounds__(256) void gam_rnnt_greedy_kernel(GamRnntArgs a) {
     if (a.dump_count != nullptr) a.dump_count[b] = n_dump;
   }
 }
+
+// ---------------------------------------------------------------------------------
+// Emotion head (reference gigaam/model.py:272-285, GigaAMEmo.get_probs): mean of the encoder
+// output over time -> Linear(d_model, n_classes) -> softmax.  One workgroup per utterance;
+// encoded is channel-first [B, D, Tp], so a wave sums one channel's contiguous Tp frames.
+// lens == nullptr: all Tp frames (what the reference's avg_pool1d over the whole axis does for
+// its single, unpadded file); otherwise the first lens[b] frames.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gam_emo_head_kernel(const float* __restrict__ enc, const int* __restrict__ lens,
+                                                           const float* __restrict__ w, const float* __restrict__ bias,
+                                                           float* __restrict__ probs, int D, int Tp, int NC) {
+  extern __shared__ float gam_smem_emo[];   // [D] pooled + [NC] logits
+  float* pooled = gam_smem_emo;
+  float* logit = gam_smem_emo + D;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int n = lens != nullptr ? lens[b] : Tp;
+  n = n < 1 ? 1 : (n > Tp ? Tp : n);
+  for (int c = wave; c < D; c += 4) {
+    const float* r = enc + ((size_t)b * D + c) * Tp;
+    float s = 0.f;
+    for (int t = lane; t < n; t += 64) s += r[t];
+    s = gam_wave_sum(s);
+    if (lane == 0) pooled[c] = s / (float)n;
+  }
+  __syncthreads();
+  for (int k = wave; k < NC; k += 4) {
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s = fmaf(w[(size_t)k * D + c], pooled[c], s);
+    s = gam_wave_sum(s);
+    if (lane == 0) logit[k] = s + bias[k];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float mx = -INFINITY;
+    for (int k = lane; k < NC; k += 64) mx = fmaxf(mx, logit[k]);
+    mx = gam_wave_max(mx);
+    float se = 0.f;
+    for (int k = lane; k < NC; k += 64) se += expf(logit[k] - mx);
+    se = gam_wave_sum(se);
+    for (int k = lane; k < NC; k += 64) probs[(size_t)b * NC + k] = expf(logit[k] - mx) / se;
+  }
+}

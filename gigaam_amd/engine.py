@@ -63,6 +63,9 @@ def build_config(pre: Any = None, enc: Any = None, head: Any = None) -> GamConfi
             c.pred_hidden = _get(dec, "pred_hidden")
             c.pred_rnn_layers = _get(dec, "pred_rnn_layers")
             c.joint_hidden = _get(jn, "joint_hidden")
+        elif target.endswith("Linear"):   # emotion model: torch.nn.Linear(in_features, out_features)
+            c.head_type = _lib.HEAD_EMO
+            c.num_classes = _get(head, "out_features")
         else:
             c.head_type = _lib.HEAD_CTC
             c.num_classes = _get(head, "num_classes")
@@ -182,6 +185,18 @@ class HipEngine:
         with torch.cuda.device(self.device):
             rc = self.lib.gam_ctc_head(self._h, _ptr(encoded), b, tp, _ptr(out), self._stream())
         self._check(rc, "gam_ctc_head")
+        return out
+
+    def emo_probs(self, encoded: Tensor, enc_len: Optional[Tensor] = None) -> Tensor:
+        """[B,d_model,T'] -> class probabilities [B,num_classes] (mean over time, Linear, softmax);
+        enc_len restricts the mean to each utterance's valid frames (None = all T')."""
+        encoded = self._dev(encoded, torch.float32)
+        enc_len = None if enc_len is None else self._dev(enc_len, torch.int32)
+        b, _, tp = encoded.shape
+        out = torch.empty((b, self.cfg.num_classes), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gam_emo_probs(self._h, _ptr(encoded), _ptr(enc_len), b, tp, _ptr(out), self._stream())
+        self._check(rc, "gam_emo_probs")
         return out
 
     def ctc_greedy(self, encoded: Tensor, enc_len: Tensor) -> Tuple[Tensor, Tensor, Tensor]:

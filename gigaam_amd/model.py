@@ -27,6 +27,7 @@ _TARGETS = {
     "ConformerEncoder": _encoder.ConformerEncoder,
     "CTCHead": _decoder.CTCHead,
     "RNNTHead": _decoder.RNNTHead,
+    "Linear": _decoder.EmoHead,   # cfg.head of the emotion model (torch.nn.Linear)
     "CTCGreedyDecoding": _decoding.CTCGreedyDecoding,
     "RNNTGreedyDecoding": _decoding.RNNTGreedyDecoding,
 }
@@ -110,6 +111,33 @@ class GigaAM(nn.Module):
     def embed_audio(self, wav_file: str) -> Tuple[Tensor, Tensor]:
         wav, length = self.prepare_wav(wav_file)
         return self.forward(wav, length)
+
+
+class GigaAMEmo(GigaAM):
+    """Emotion recognition model (reference gigaam/model.py:262-285): encoder + time pooling +
+    linear head + softmax; ``cfg.id2name`` maps class index -> name."""
+
+    def __init__(self, cfg: Any):
+        super().__init__(cfg)
+        self.head = instantiate(_node(cfg, "head"))
+        self.id2name = _plain(_node(cfg, "id2name"))
+
+    def _head_cfg(self) -> Any:
+        return _node(self.cfg, "head")
+
+    def get_probs(self, wav_file: str) -> Dict[str, float]:
+        wav, length = self.prepare_wav(wav_file)
+        encoded, _ = self.forward(wav, length)
+        # the reference pools over the whole T' axis of its single, unpadded file (model.py:278-280)
+        probs = self.head.probs(encoded)[0].tolist()
+        names = self.id2name
+        return {(names[i] if not isinstance(names, dict) else names.get(i, names.get(str(i)))): probs[i] for i in range(len(probs))}
+
+    def get_probs_batch(self, wav: Tensor, lengths: Tensor) -> Tensor:
+        """Batched variant: wav [B,L], lengths [B] -> probabilities [B,n_classes]; the mean runs over each
+        utterance's valid encoder frames."""
+        encoded, enc_len = self.forward(wav.to(self._device), lengths.to(self._device))
+        return self.head.probs(encoded, enc_len)
 
 
 class GigaAMASR(GigaAM):

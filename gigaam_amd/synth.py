@@ -78,6 +78,9 @@ def _pre_cfg(v3: bool) -> Dict[str, Any]:
     return cfg
 
 
+EMO_NAMES = ["angry", "sad", "neutral", "positive"]
+
+
 def _ctc_head(v: int) -> Dict[str, Any]:
     return {"_target_": "gigaam.decoder.CTCHead", "feat_in": 768, "num_classes": v}
 
@@ -122,6 +125,10 @@ def model_cfg(model_name: str, **encoder_overrides: Any) -> Dict[str, Any]:
         "encoder": enc,
     }
     if name.endswith("ssl"):
+        return cfg
+    if name == "emo":   # emotion model: conv2d-stem encoder + Linear head (gigaam/model.py:262-285)
+        cfg["head"] = {"_target_": "torch.nn.Linear", "in_features": 768, "out_features": len(EMO_NAMES)}
+        cfg["id2name"] = {i: n for i, n in enumerate(EMO_NAMES)}
         return cfg
     e2e = "e2e" in name
     vocab = _e2e_vocab(256 if name.endswith("e2e_ctc") else 1024) if e2e else CHAR_VOCAB
@@ -261,7 +268,11 @@ def make_state_dict(cfg: Dict[str, Any], seed: int = 0,
     # dominates a random-weight encoder).  Folding -W.calib into the head bias
     # makes the decode depend on the time-varying part, i.e. non-degenerate.
     c = torch.zeros(d) if calib is None else calib.to(torch.float32)
-    if head["_target_"].endswith("CTCHead"):
+    if head["_target_"].endswith("Linear"):
+        nc = head["out_features"]
+        _linear(sd, rng, "head", nc, head["in_features"], gain=6.0)
+        sd["head.bias"] -= sd["head.weight"] @ c
+    elif head["_target_"].endswith("CTCHead"):
         v = head["num_classes"]
         # large gain: top-1/top-2 logit margins >> fp32 noise; mild blank bias
         _linear(sd, rng, "head.decoder_layers.0", v, head["feat_in"], shape=(v, head["feat_in"], 1), gain=6.0)

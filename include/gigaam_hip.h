@@ -13,6 +13,7 @@
  *   gam_ctc_greedy   <- CTCGreedyDecoding.decode          gigaam/decoding.py:56-96
  *   gam_rnnt_greedy  <- RNNTGreedyDecoding.decode         gigaam/decoding.py:128-207
  *                        (+ RNNTDecoder.predict decoder.py:85-102, RNNTJoint.joint :41-47)
+ *   gam_emo_probs    <- GigaAMEmo.get_probs (pool+head)    gigaam/model.py:272-285
  *   gam_set_weight   <- nn.Module.load_state_dict         gigaam/__init__.py:185
  *   gam_create       <- hydra.utils.instantiate(cfg.*)    gigaam/model.py:24-25,93-94
  *
@@ -44,7 +45,7 @@ typedef struct gam_handle gam_handle;
 enum { GAM_SUBS_CONV2D = 0, GAM_SUBS_CONV1D = 1 };
 enum { GAM_ATT_ROTARY = 0, GAM_ATT_REL_POS = 1 };
 enum { GAM_NORM_BATCH = 0, GAM_NORM_LAYER = 1 };
-enum { GAM_HEAD_NONE = 0, GAM_HEAD_CTC = 1, GAM_HEAD_RNNT = 2 };
+enum { GAM_HEAD_NONE = 0, GAM_HEAD_CTC = 1, GAM_HEAD_RNNT = 2, GAM_HEAD_EMO = 3 };
 enum { GAM_DTYPE_F32 = 0, GAM_DTYPE_F16 = 1, GAM_DTYPE_BF16 = 2, GAM_DTYPE_F64 = 3, GAM_DTYPE_I64 = 4 };
 
 /* POD mirror of the four cfg sub-trees of a GigaAM checkpoint. */
@@ -55,7 +56,8 @@ typedef struct gam_config {
   int32_t feat_in, n_layers, d_model, subsampling, subs_kernel_size, subsampling_factor;
   int32_t ff_expansion_factor, self_attention_model, n_heads, pos_emb_max_len;
   int32_t conv_norm_type, conv_kernel_size;
-  /* cfg.head -- CTCHead(feat_in, num_classes) decoder.py:12-16 | RNNTHead(decoder, joint) :146-149 */
+  /* cfg.head -- CTCHead(feat_in, num_classes) decoder.py:12-16 | RNNTHead(decoder, joint) :146-149 |
+   * emotion model: a Linear(d_model, num_classes) (model.py:267-270; keys head.weight / head.bias) */
   int32_t head_type, num_classes, pred_hidden, pred_rnn_layers, joint_hidden;
 } gam_config;
 
@@ -109,6 +111,12 @@ int gam_ctc_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len, 
 int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len, int B, int64_t Tp,
                     int max_symbols, int32_t* ids, int32_t* frames, int32_t* counts,
                     float* logits_dump, int32_t* dump_count, int dump_cap, void* stream);
+
+/* GigaAMEmo.get_probs after the encoder (model.py:277-283): mean over time of encoded f32 [B,d_model,T'],
+ * Linear, softmax -> probs f32 [B,num_classes].  enc_len i32 [B] restricts the mean to the valid frames of
+ * each utterance; NULL = all T' frames (the reference pools its single unpadded file over the whole axis). */
+int gam_emo_probs(gam_handle* h, const float* encoded, const int32_t* enc_len, int B, int64_t Tp, float* probs,
+                  void* stream);
 
 /* Arithmetic of the dense contractions (every other kernel is plain fp32):
  *   GAM_GEMM_F32   -- v_mfma_f32_32x32x2_f32, bit-for-bit an fp32 fmaf chain.

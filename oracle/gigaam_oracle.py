@@ -384,6 +384,19 @@ def rnnt_greedy(sd: SD, encoded: Tensor, enc_len: Tensor, max_symbols: int = 10,
 # =========================================================================== #
 # a15 glue: wav -> ids   (model.py:27-37,96-140)
 # =========================================================================== #
+def emo_probs(sd: SD, encoded: Tensor, enc_len: Optional[Tensor] = None) -> Tensor:
+    """GigaAMEmo.get_probs after the encoder (reference gigaam/model.py:277-283; the export twin
+    :291-293 writes the same thing as encoded.mean(-1)): avg_pool1d over the whole T' axis ->
+    head (a Linear; keys head.weight / head.bias) -> softmax.  enc_len (not in the reference, which
+    only ever sees one unpadded file) restricts the mean to each utterance's valid frames."""
+    if enc_len is None:
+        pooled = F.avg_pool1d(encoded, kernel_size=encoded.shape[-1]).squeeze(-1)
+    else:
+        m = (torch.arange(encoded.shape[-1])[None, :] < enc_len[:, None]).to(encoded.dtype)
+        pooled = (encoded * m[:, None, :]).sum(-1) / enc_len.clamp(min=1)[:, None].to(encoded.dtype)
+    return torch.softmax(F.linear(pooled, sd["head.weight"], sd["head.bias"]), dim=-1)
+
+
 def transcribe_ids(ckpt: dict, wav: Tensor, lengths: Tensor):
     """Full CPU pipeline on a ``{"cfg","state_dict"}`` checkpoint.
     Returns (decoded [(ids, frames)], encoded, enc_len)."""

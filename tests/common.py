@@ -22,6 +22,7 @@ CASES = {
     "v1_ctc_l2": ("v1_ctc", 1, 2, (3, 3.0, 16, [48000, 40000, 20000])),
     "v2_ctc_l2_short": ("v2_ctc", 1, 2, (2, 0.3125, 17, [5000, 3200])),
 }
+EMO_CASE = ("emo", 1, 2, (2, 3.0, 18, [48000, 36000]))   # tests/golden/emo_l2.npz
 
 # tolerances (fp32 vs fp32, different summation orders)
 TOL_FEAT = 2e-3      # log-mel, natural-log units (small-power bins amplify round-off)

@@ -31,6 +31,7 @@ CASES = {
     "v3_e2e_rnnt_l2": ("v3_e2e_rnnt", 1, 2, (2, 3.0, 15, [48000, 30011])),
     "v1_ctc_l2": ("v1_ctc", 1, 2, (3, 3.0, 16, [48000, 40000, 20000])),
     "v2_ctc_l2_short": ("v2_ctc", 1, 2, (2, 0.3125, 17, [5000, 3200])),  # reference tests/test_batching.py:125-140
+    "emo_l2": ("emo", 1, 2, (2, 3.0, 18, [48000, 36000])),
 }
 
 
@@ -68,6 +69,35 @@ def run_case(ref, case):
         stats = {"enc_absdiff_oracle_vs_ref": d_enc, "pre_absdiff": d_pre}
 
         head_sd = strip(sd, "head.")
+        if cfg["head"]["_target_"].endswith("Linear"):
+            # the reference's own GigaAMEmo methods (gigaam/model.py:272-293), run unbound on a stand-in
+            # `self` whose encoder / head are the reference encoder above and a torch Linear
+            import importlib
+            import types
+            sys.modules["hydra"].utils.instantiate = lambda *a, **k: None
+            ref_model = importlib.import_module("gigaam.model")
+            lin = torch.nn.Linear(cfg["head"]["in_features"], cfg["head"]["out_features"])
+            lin.load_state_dict(head_sd)
+            fake = types.SimpleNamespace(encoder=enc, head=lin, id2name=cfg["id2name"])
+            p_export = ref_model.GigaAMEmo.forward_for_export(fake, feat, flen)          # whole-axis mean, batch
+            single = []
+            for i in range(b):   # get_probs: one unpadded file at a time (model.py:276-283)
+                f1, l1 = O.log_mel(wav[i:i + 1, : int(wlen[i])], wlen[i:i + 1], cfg["preprocessor"],
+                                   sd["preprocessor.featurizer.0.spectrogram.window"], sd["preprocessor.featurizer.0.mel_scale.fb"])
+                fake.prepare_wav = lambda _f, f1=f1, l1=l1: (f1, l1)
+                fake.forward = lambda x, l: enc(x, l)
+                d = ref_model.GigaAMEmo.get_probs(fake, "unused.wav")
+                single.append([d[cfg["id2name"][k]] for k in range(len(d))])
+            p_single = torch.tensor(single)
+            assert float((O.emo_probs(sd, y_ref) - p_export).abs().max()) < 1e-6
+            y1 = [enc(*O.log_mel(wav[i:i + 1, : int(wlen[i])], wlen[i:i + 1], cfg["preprocessor"],
+                                 sd["preprocessor.featurizer.0.spectrogram.window"], sd["preprocessor.featurizer.0.mel_scale.fb"]))[0]
+                  for i in range(b)]
+            p_or_single = torch.cat([O.emo_probs(sd, y) for y in y1])
+            assert float((p_or_single - p_single).abs().max()) < 1e-6
+            out.update(probs_export=p_export.numpy(), probs_single=p_single.numpy())
+            stats["probs_single"] = p_single.tolist()
+            return out, stats
         if cfg["head"]["_target_"].endswith("CTCHead"):
             head = ref.decoder.CTCHead(**kw(cfg["head"])).eval()
             head.load_state_dict(head_sd)

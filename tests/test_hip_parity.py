@@ -171,6 +171,38 @@ def test_rnnt_ids_frames_and_logits(case, mode):
     assert got2 == ref or min(margins) < 1e-3
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_emotion_model_probs(mode):
+    """GigaAMEmo path (model.py:272-293): encoder -> gam_emo_probs against the reference's committed
+    probabilities (tests/golden/emo_l2.npz), the reference tolerance for this output is 1e-3
+    (reference tests/test_loading.py:39-42)."""
+    import os
+    from common import EMO_CASE, ROOT
+    from gigaam_amd import synth
+    model, seed, nl, (b, secs, aseed, lens) = EMO_CASE
+    ck = synth.make_checkpoint(model, seed=seed, n_layers=nl)
+    wav, wlen = synth.synth_audio(b, secs, seed=aseed, lengths=lens)
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "emo_l2.npz")))
+    eng = _engine(ck, mode)
+    enc, elen = eng.encode(*eng.frontend(wav, wlen))
+    # whole-axis mean (forward_for_export) on the utterance that fills the batch; shorter ones would
+    # average the padded frames too, which this encoder leaves as don't-care values
+    p_all = eng.emo_probs(enc).cpu()
+    assert float((p_all[0] - torch.from_numpy(gold["probs_export"][0])).abs().max()) < 1e-4
+    want_m = O.emo_probs(ck["state_dict"], torch.from_numpy(gold["encoded"]), torch.from_numpy(gold["enc_len"]))
+    assert float((eng.emo_probs(enc, elen).cpu() - want_m).abs().max()) < 1e-4
+    # head alone on the reference's encoder output, and the masked-mean variant against the oracle
+    enc_ref = torch.from_numpy(gold["encoded"])
+    assert float((eng.emo_probs(enc_ref).cpu() - torch.from_numpy(gold["probs_export"])).abs().max()) < 1e-5
+    elen_ref = torch.from_numpy(gold["enc_len"])
+    want = O.emo_probs(ck["state_dict"], enc_ref, elen_ref)
+    assert float((eng.emo_probs(enc_ref, elen_ref).cpu() - want).abs().max()) < 1e-5
+    for i in range(b):   # get_probs: one unpadded file
+        e1, _ = eng.encode(*eng.frontend(wav[i:i + 1, : int(wlen[i])].contiguous(), wlen[i:i + 1]))
+        p = eng.emo_probs(e1).cpu()[0]
+        assert float((p - torch.from_numpy(gold["probs_single"][i])).abs().max()) < 1e-4
+
+
 def test_batched_equals_single_and_edge_lengths():
     """reference tests/test_batching.py:35-122: features are computed per sample, then the
     zero-padded batch through the encoder must equal each sample alone on its valid frames
@@ -247,3 +279,30 @@ def test_model_api_transcribe(tmp_path):
     assert len(a1) == len(a3) == 4 and [s.text for s in a3] == manual and bounds == regs
     assert [s.text for s in a1] == [model.transcribe_batch(c[None], torch.tensor([c.shape[0]]))[0][0] for c in segs]
     assert [(s.start, s.end) for s in a3] == regs and a3.has_word_timestamps
+
+
+def test_model_api_emotion(tmp_path):
+    """load_model() -> GigaAMEmo.get_probs(wav_file) -> {name: prob} (reference model.py:272-285)."""
+    import wave
+    import gigaam_amd
+    from gigaam_amd import synth
+    ck = synth.make_checkpoint("emo", seed=1, n_layers=2)
+    path = str(tmp_path / "emo.ckpt")
+    torch.save(ck, path)
+    model = gigaam_amd.load_model(path, device="cuda:0")
+    assert isinstance(model, gigaam_amd.GigaAMEmo)
+    wav, _ = synth.synth_audio(1, 3.0, seed=5)
+    pcm = (wav[0].numpy() * 32768.0).round().clip(-32768, 32767).astype(np.int16)
+    wpath = str(tmp_path / "clip.wav")
+    with wave.open(wpath, "wb") as wf:
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000); wf.writeframes(pcm.tobytes())
+    probs = model.get_probs(wpath)
+    assert list(probs) == synth.EMO_NAMES and abs(sum(probs.values()) - 1.0) < 1e-5
+    x = torch.from_numpy(pcm.astype(np.float32) / 32768.0)[None]
+    with torch.no_grad():
+        feat, flen = oracle_features(ck, x, torch.tensor([x.shape[1]]))
+        enc, _ = O.encoder_forward(ck["state_dict"], ck["cfg"]["encoder"], feat, flen)
+        want = O.emo_probs(ck["state_dict"], enc)[0]
+    assert max(abs(probs[n] - float(want[i])) for i, n in enumerate(synth.EMO_NAMES)) < 1e-3   # reference bar: ±1e-3
+    pb = model.get_probs_batch(x.repeat(2, 1), torch.tensor([x.shape[1], x.shape[1]])).cpu()
+    assert float((pb[0] - pb[1]).abs().max()) < 1e-6 and float((pb[0] - want).abs().max()) < 1e-3

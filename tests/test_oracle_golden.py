@@ -38,6 +38,30 @@ def test_oracle_matches_reference_golden(case):
     assert got == ref
 
 
+def test_emotion_head_oracle_matches_reference_golden():
+    """GigaAMEmo (model.py:272-293): tests/golden/emo_l2.npz holds what the reference's own get_probs /
+    forward_for_export bodies returned (make_golden.py runs them unbound on the reference encoder)."""
+    import os
+    from common import EMO_CASE, ROOT
+    from gigaam_amd import synth
+    model, seed, nl, (b, secs, aseed, lens) = EMO_CASE
+    ck = synth.make_checkpoint(model, seed=seed, n_layers=nl)
+    wav, wlen = synth.synth_audio(b, secs, seed=aseed, lengths=lens)
+    gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "emo_l2.npz")))
+    sd, cfg = ck["state_dict"], ck["cfg"]
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        feat, flen = oracle_features(ck, wav, wlen)
+        enc, elen = O.encoder_forward(sd, cfg["encoder"], feat, flen)
+        assert float((O.emo_probs(sd, enc) - torch.from_numpy(gold["probs_export"])).abs().max()) < 1e-5
+        for i in range(b):   # one unpadded file at a time, as get_probs does
+            f1, l1 = oracle_features(ck, wav[i:i + 1, : int(wlen[i])], wlen[i:i + 1])
+            e1, _ = O.encoder_forward(sd, cfg["encoder"], f1, l1)
+            p = O.emo_probs(sd, e1)[0]
+            assert abs(float(p.sum()) - 1.0) < 1e-6
+            assert float((p - torch.from_numpy(gold["probs_single"][i])).abs().max()) < 1e-5
+
+
 def test_frontend_known_answers():
     """a1 is parity-unpinned (no torchaudio here): analytic checks of the restatement."""
     from gigaam_amd import synth
