@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=20.0)
     ap.add_argument("--layers", type=int, default=-1, help="debug only: fewer layers INVALIDATES the number")
     ap.add_argument("--cpu-utts", type=int, default=8, help="utterances in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--rnnt-blank-bias", type=float, default=None,
+                    help="RNN-T models: blank bias of the synthetic joint (default: emission-heavy synthetic head)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--gemm", default="f16x3", choices=["f16x3", "f32"],
                     help="dense-contraction arithmetic: split-fp16 MFMA (fp32-equivalent, default) or exact fp32 MFMA")
@@ -139,7 +141,7 @@ def main():
     from gigaam_amd import synth
 
     over = {} if args.layers < 0 else {"n_layers": args.layers}
-    ckpt = synth.make_checkpoint(args.model, seed=0, **over)
+    ckpt = synth.make_checkpoint(args.model, seed=0, rnnt_blank_bias=args.rnnt_blank_bias, **over)
     model = gigaam_amd.model_from_checkpoint(ckpt, dev)
     eng = model.encoder.engine
     eng.set_gemm_mode(args.gemm)

@@ -186,11 +186,14 @@ class GigaAMASR(GigaAM):
                             fr_num_workers: int = 0, **kwargs: Any) -> LongformTranscriptionResult:
         """Segment -> zero-padded batches of ``fr_batch_size`` -> transcribe -> stitch
         (reference model.py:195-259).  The reference segments with pyannote's VAD
-        (gated third-party model, not installable here); pass ``speech_regions=[(s,e),..]``
-        or ``vad=callable(wav, sr) -> regions`` and the reference's own chunk packer
+        (gated third-party model, not installable here); pass ``speech_regions=[(s,e),..]``,
+        ``vad=callable(wav, sr) -> regions`` or ``vad="energy"`` (vad_utils.EnergyVAD, a labelled
+        stand-in) and the reference's own chunk packer
         (vad_utils.pack_regions) does the rest."""
-        from .vad_utils import segment_audio_file
+        from .vad_utils import EnergyVAD, segment_audio_file
 
+        if kwargs.get("vad") == "energy":   # stand-in detector on the HIP frontend (NOT pyannote)
+            kwargs["vad"] = EnergyVAD(self.preprocessor)
         segments, boundaries = segment_audio_file(wav_file, SAMPLE_RATE, device=self._device, **kwargs)
         if not segments:
             return LongformTranscriptionResult(segments=[])

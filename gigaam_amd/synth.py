@@ -202,7 +202,7 @@ def _norm(sd, rng, prefix, d):
 
 
 def make_state_dict(cfg: Dict[str, Any], seed: int = 0,
-                    calib: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+                    calib: Optional[torch.Tensor] = None, rnnt_blank_bias: Optional[float] = None) -> Dict[str, torch.Tensor]:
     rng = _Rng(seed)
     sd: Dict[str, torch.Tensor] = {}
     pre = cfg["preprocessor"]
@@ -295,7 +295,9 @@ def make_state_dict(cfg: Dict[str, Any], seed: int = 0,
         sd["head.joint.enc.bias"] -= sd["head.joint.enc.weight"] @ c
         _linear(sd, rng, "head.joint.joint_net.1", jn["num_classes"], jn["joint_hidden"], gain=4.0)
         # blank bias: a trained transducer emits blank on most frames
-        sd["head.joint.joint_net.1.bias"][v - 1] += 5.3 + 0.35 * math.log(v)
+        # (default: emission-heavy, several symbols per frame -- exercises max_symbols_per_step;
+        #  rnnt_blank_bias overrides it, e.g. to a speech-like rate of a few tokens per second)
+        sd["head.joint.joint_net.1.bias"][v - 1] += (5.3 + 0.35 * math.log(v)) if rnnt_blank_bias is None else rnnt_blank_bias
     return sd
 
 
@@ -315,12 +317,13 @@ def load_calib(cfg: Dict[str, Any], seed: int) -> Optional[torch.Tensor]:
     return None
 
 
-def make_checkpoint(model_name: str, seed: int = 0, calib="auto", **encoder_overrides: Any) -> Dict[str, Any]:
+def make_checkpoint(model_name: str, seed: int = 0, calib="auto", rnnt_blank_bias: Optional[float] = None,
+                    **encoder_overrides: Any) -> Dict[str, Any]:
     """``calib``: "auto" = committed vector if there is one, None = zeros, or a tensor."""
     cfg = model_cfg(model_name, **encoder_overrides)
     if isinstance(calib, str):
         calib = load_calib(cfg, seed)
-    return {"cfg": copy.deepcopy(cfg), "state_dict": make_state_dict(cfg, seed, calib)}
+    return {"cfg": copy.deepcopy(cfg), "state_dict": make_state_dict(cfg, seed, calib, rnnt_blank_bias)}
 
 
 def synth_audio(batch: int, seconds: float, seed: int = 0, sample_rate: int = 16000,

@@ -3,7 +3,10 @@
 The reference obtains speech regions from pyannote's VoiceActivityDetection
 pipeline (a gated third-party network; SURVEY.md §2.1 row 8 marks the model out
 of scope) and then packs them into 15-22 s chunks with a 30 s hard cap.  Only the
-packing is restated here; regions come from the caller.
+packing is restated here; regions come from the caller, or from ``EnergyVAD`` -- a
+log-mel-energy detector on the HIP frontend that is a STAND-IN, NOT the reference's
+pyannote model (different decisions on real speech; it only makes the longform path
+runnable end to end without the gated network).
 """
 from __future__ import annotations
 
@@ -63,3 +66,59 @@ def segment_audio_file(wav_file: str, sr: int, device=None,
         speech_regions = vad(audio, sr)
     bounds = pack_regions(speech_regions, audio.shape[0] / sr, **pack_kwargs)
     return [audio[int(s * sr): int(e * sr)] for s, e in bounds], bounds
+
+
+class EnergyVAD:
+    """Energy-based voice activity detector -- a stand-in for the reference's pyannote pipeline
+    (reference gigaam/vad_utils.py:41-77), NOT a reimplementation of it.
+
+    Frame energies are the mean log-mel of the model's own HIP frontend (10 ms hop, computed on
+    the GPU a minute at a time); the decision logic is a few lines of host code: a threshold
+    between the 10th and 95th percentile of the file's frame energies, then the same kind of
+    post-processing pyannote's pipeline applies (drop speech shorter than ``min_duration_on``,
+    fill pauses shorter than ``min_duration_off``)."""
+
+    def __init__(self, preprocessor, threshold: float = 0.35, min_duration_on: float = 0.25,
+                 min_duration_off: float = 0.25, pad: float = 0.05, floor_db: float = 6.0):
+        self.pre = preprocessor
+        self.threshold, self.min_on, self.min_off, self.pad, self.floor_db = threshold, min_duration_on, min_duration_off, pad, floor_db
+
+    @torch.inference_mode()
+    def frame_energy(self, audio: Tensor, sr: int) -> Tensor:
+        dev = self.pre.engine.device
+        hop = self.pre.hop_length
+        step = 60 * sr // hop * hop              # whole frames per piece
+        out = []
+        for i in range(0, audio.shape[0], step):
+            piece = audio[i:i + step]
+            if piece.shape[0] < self.pre.win_length:
+                break
+            feat, n = self.pre(piece[None].to(dev, torch.float32), torch.tensor([piece.shape[0]], device=dev))
+            k = min(int(n[0]), piece.shape[0] // hop)        # frames that start inside this piece
+            out.append(feat[0, :, :k].mean(dim=0).cpu())
+        return torch.cat(out) if out else torch.zeros(0)
+
+    def __call__(self, audio: Tensor, sr: int) -> List[Tuple[float, float]]:
+        e = self.frame_energy(audio, sr)
+        if e.numel() == 0:
+            return []
+        hop_s = self.pre.hop_length / sr
+        lo, hi = torch.quantile(e, 0.10).item(), torch.quantile(e, 0.95).item()
+        if hi - lo < self.floor_db * 0.2303:      # natural-log units: no dynamic range -> one region
+            return [(0.0, audio.shape[0] / sr)]
+        active = (e > lo + self.threshold * (hi - lo)).tolist()
+        runs, start = [], None
+        for i, a in enumerate(active + [False]):
+            if a and start is None:
+                start = i
+            elif not a and start is not None:
+                runs.append([start * hop_s, i * hop_s])
+                start = None
+        merged: List[List[float]] = []
+        for r in runs:                            # fill short pauses, then drop short speech
+            if merged and r[0] - merged[-1][1] < self.min_off:
+                merged[-1][1] = r[1]
+            else:
+                merged.append(r)
+        total = audio.shape[0] / sr
+        return [(max(0.0, a - self.pad), min(total, b + self.pad)) for a, b in merged if b - a >= self.min_on]
