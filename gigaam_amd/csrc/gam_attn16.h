@@ -25,8 +25,14 @@ __device__ __forceinline__ void gam_split8(const float (&v)[8], gam_half8& hi, g
   }
 }
 
+// REL: the relative-position scores of v1 models (gam_attn.h, reference encoder.py:191-228):
+//   S[i,j] = ((q_i + u).k_j + (q_i + v).P(i - j)) / sqrt(d_k); the second term is evaluated per key
+// tile as G[m][query] = P(rlo + m).(q + v) for the 80 relative positions the (16 queries x 64 keys)
+// block touches -- same three-term split, P rows split on the fly -- and skewed into S^T through LDS.
+template <bool REL>
 __global__ __launch_bounds__(256) void gam_attn_f16x3_kernel(GamAttnArgs a) {
   a.scale *= 1.44269504088896341f;   // softmax via 2^x: p = 2^(s*log2e - m)
+  __shared__ float Gs[REL ? 4 * 80 * 17 : 1];   // per wave: (q+v).P for 80 relative positions x 16 queries
   __shared__ __attribute__((aligned(16))) _Float16 Kh[GAM_ATT_KT * GAM_A16_KLD];
   __shared__ __attribute__((aligned(16))) _Float16 Kl[GAM_ATT_KT * GAM_A16_KLD];
   __shared__ __attribute__((aligned(16))) _Float16 Vh[GAM_ATT_DK * GAM_A16_VLD];
@@ -43,6 +49,8 @@ __global__ __launch_bounds__(256) void gam_attn_f16x3_kernel(GamAttnArgs a) {
   // Q fragments (B operand of S^T), pre-scaled: x32 part d = 8*lg .. +7, x16 part d = 32 + 4*lg .. +3
   gam_half8 qh32[2], ql32[2];
   gam_half4 qh16[2], ql16[2];
+  gam_half8 gh32[2], gl32[2];   // REL: (q + pos_bias_v) * scale
+  gam_half4 gh16[2], gl16[2];
   int qrow[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -53,11 +61,23 @@ __global__ __launch_bounds__(256) void gam_attn_f16x3_kernel(GamAttnArgs a) {
     const float4 q0 = *reinterpret_cast<const float4*>(qp + 8 * lg);
     const float4 q1 = *reinterpret_cast<const float4*>(qp + 8 * lg + 4);
     const float4 q2 = *reinterpret_cast<const float4*>(qp + 32 + 4 * lg);
-    const float v8[8] = {q0.x * a.scale, q0.y * a.scale, q0.z * a.scale, q0.w * a.scale,
-                         q1.x * a.scale, q1.y * a.scale, q1.z * a.scale, q1.w * a.scale};
+    float v8[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    float v4[4] = {q2.x, q2.y, q2.z, q2.w};
+    if (REL) {
+      const float* pu = a.pos_u + h * DK;
+      const float* pv = a.pos_v + h * DK;
+      float g8[8], g4[4];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { g8[e] = (v8[e] + pv[8 * lg + e]) * a.scale; v8[e] += pu[8 * lg + e]; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { g4[e] = (v4[e] + pv[32 + 4 * lg + e]) * a.scale; v4[e] += pu[32 + 4 * lg + e]; }
+      gam_split8(g8, gh32[j], gl32[j]);
+      gam_split4((f32x4){g4[0], g4[1], g4[2], g4[3]}, gh16[j], gl16[j]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v8[e] *= a.scale;
     gam_split8(v8, qh32[j], ql32[j]);
-    const f32x4 v4 = {q2.x * a.scale, q2.y * a.scale, q2.z * a.scale, q2.w * a.scale};
-    gam_split4(v4, qh16[j], ql16[j]);
+    gam_split4((f32x4){v4[0] * a.scale, v4[1] * a.scale, v4[2] * a.scale, v4[3] * a.scale}, qh16[j], ql16[j]);
   }
 
   f32x4 o[3][2];
@@ -127,6 +147,46 @@ __global__ __launch_bounds__(256) void gam_attn_f16x3_kernel(GamAttnArgs a) {
         s16 = __builtin_amdgcn_mfma_f32_16x16x16f16(kh16, qh16[j], s16, 0, 0, 0);
         s += s16;
         st[kb][j] = s;
+      }
+    }
+
+    if (REL) {
+      // ---- S^T[key a][query b] += G[b - a + 63][b],  G[m][b] = P(rlo + m) . (q_b + v) ----
+      float* gw = Gs + wave * (80 * 17);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int rlo = (qw0 + j * 16) - kt0 - 63 + (a.Tv - 1);   // pbuf row of m = 0
+#pragma unroll
+        for (int mt = 0; mt < 5; ++mt) {
+          int prow = rlo + mt * 16 + li;
+          prow = prow < 0 ? 0 : (prow > 2 * a.Tv - 2 ? 2 * a.Tv - 2 : prow);
+          const float* pp = a.pbuf + (size_t)prow * a.ldp + h * DK;
+          const float4 p0 = *reinterpret_cast<const float4*>(pp + 8 * lg);
+          const float4 p1 = *reinterpret_cast<const float4*>(pp + 8 * lg + 4);
+          const float4 p2 = *reinterpret_cast<const float4*>(pp + 32 + 4 * lg);
+          const float p8[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+          gam_half8 ph32, pl32;
+          gam_half4 ph16, pl16;
+          gam_split8(p8, ph32, pl32);
+          gam_split4((f32x4){p2.x, p2.y, p2.z, p2.w}, ph16, pl16);
+          f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
+          f32x4 g16 = (f32x4){0.f, 0.f, 0.f, 0.f};   // one chain per MFMA shape (see below)
+          g = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl32, gh32[j], g, 0, 0, 0);
+          g16 = __builtin_amdgcn_mfma_f32_16x16x16f16(pl16, gh16[j], g16, 0, 0, 0);
+          g = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph32, gl32[j], g, 0, 0, 0);
+          g16 = __builtin_amdgcn_mfma_f32_16x16x16f16(ph16, gl16[j], g16, 0, 0, 0);
+          g = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph32, gh32[j], g, 0, 0, 0);
+          g16 = __builtin_amdgcn_mfma_f32_16x16x16f16(ph16, gh16[j], g16, 0, 0, 0);
+          g += g16;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) gw[(mt * 16 + lg * 4 + r) * 17 + li] = g[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[kb][j][r] += gw[(li - (kb * 16 + lg * 4 + r) + 63) * 17 + li];
+        __syncthreads();
       }
     }
 
@@ -212,12 +272,12 @@ __global__ __launch_bounds__(256) void gam_attn_f16x3_kernel(GamAttnArgs a) {
   }
 }
 
-// split = true: fp16-split MFMA path (rotary / plain SDPA only); the relative-position
-// variant always runs the fp32-MFMA kernel
+// split = true: fp16-split MFMA path; false: exact-fp32 MFMA path (gam_attn.h)
 static inline hipError_t gam_launch_attn_mode(const GamAttnArgs& a, int dk, bool split, hipStream_t s) {
-  if (!split || a.pbuf != nullptr) return gam_launch_attn(a, dk, s);
+  if (!split) return gam_launch_attn(a, dk, s);
   if (dk != GAM_ATT_DK) return hipErrorInvalidValue;
   dim3 grid(gam_cdiv(a.Ta, 128), a.H, a.B);
-  hipLaunchKernelGGL(gam_attn_f16x3_kernel, grid, dim3(256), 0, s, a);
+  if (a.pbuf != nullptr) hipLaunchKernelGGL(gam_attn_f16x3_kernel<true>, grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gam_attn_f16x3_kernel<false>, grid, dim3(256), 0, s, a);
   return hipGetLastError();
 }

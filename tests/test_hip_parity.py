@@ -52,7 +52,9 @@ def test_gemm_kernel_shapes_and_epilogues(mode):
     # asymmetric operands, ragged M/N edges, all activations (transposes / layout slips cannot hide)
     # the last three shapes reach the many-tile variants (128x128 phase-separated, 256x128)
     for (m, n, k, act) in [(128, 128, 32, 0), (300, 200, 64, 0), (1000, 768, 768, 1), (257, 34, 768, 0), (515, 1536, 96, 2), (1, 1, 32, 0),
-                           (16064, 768, 64, 0), (16064, 3072, 64, 1), (33000, 1536, 32, 2)]:
+                           (16064, 768, 64, 0), (16064, 3072, 64, 1), (33000, 1536, 32, 2),
+                           # steady-state k-loop of the large-batch kernel (192x256 / 256x256 tiles, LDS-DMA)
+                           (16064, 768, 768, 0), (16064, 3072, 768, 1), (8000, 768, 3072, 0), (4016, 1536, 768, 2)]:
         a = torch.randn(m, k, generator=g)
         w = torch.randn(n, k, generator=g) / k ** 0.5
         b = torch.randn(n, generator=g)
@@ -60,6 +62,12 @@ def test_gemm_kernel_shapes_and_epilogues(mode):
         ref = ref * torch.sigmoid(ref) if act == 1 else (torch.relu(ref) if act == 2 else ref)
         out = eng.op_gemm(a, w, b, act).cpu().double()
         assert float((out - ref).abs().max()) < 2e-5 * max(1.0, float(ref.abs().max())), (m, n, k, act)
+    # race screen of the DMA / barrier pipeline: reruns of a deep-k large GEMM are bit-identical
+    a = torch.randn(16064, 1536, generator=g).cuda()
+    w = (torch.randn(768, 1536, generator=g) / 1536 ** 0.5).cuda()
+    first = eng.op_gemm(a, w)
+    for _ in range(6):
+        assert torch.equal(eng.op_gemm(a, w), first)
     eye = torch.eye(64)
     w = torch.arange(96 * 64, dtype=torch.float32).reshape(96, 64) / 100.0
     got = eng.op_gemm(eye, w).cpu()
