@@ -101,6 +101,16 @@ struct gam_handle {
   int sp_min_m = GAM_SP_MIN_M;   // GAM_SP_MIN_M overrides (tests force the sp path at small sizes)
   DevBuf op_planes, op_sp, splitk_ws;   // gam_op_gemm operand planes; split-K partial sums
   int use_splitk = 1;   // GAM_SPLITK=0 disables split-K for small grids
+  // hipGraph replay of the Conformer-layer launch sequence for small batches (launch-bound: a 5 s clip is
+  // ~450 launches of 5-25 us).  Keyed on the shape; captured the second time a shape is seen (the first
+  // call sizes every workspace and sets the kernel attributes); dropped whenever a workspace buffer moves.
+  int use_graph = 1;            // GAM_GRAPH=0 disables
+  int graph_max_rows = 2048;    // only below the large-batch (sp32) regime
+  uint64_t ws_generation = 0;   // bumped by every workspace (re)allocation
+  struct GraphEntry { uint64_t gen = 0; int seen = 0; hipGraphExec_t exec = nullptr; };
+  std::map<std::vector<int>, GraphEntry> graphs;
+  long graph_replays = 0, graph_captures_failed = 0;
+  hipStream_t cap_stream = nullptr;   // private stream for captures (the caller's may be the legacy default stream)
   int* lens = nullptr;  // 4 * maxB ints: len0, len1, len2, enc_len
   int lens_cap = 0;
 
@@ -146,6 +156,7 @@ int ensure(gam_handle* h, DevBuf& b, size_t floats) {
   b.cap = 0;
   HIPCHK(h, hipMalloc(&b.p, floats * sizeof(float)));
   b.cap = floats;
+  ++h->ws_generation;   // captured graphs hold the old pointers
   return 0;
 }
 
@@ -362,6 +373,7 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   if (const char* e = getenv("GAM_SP")) h->use_sp = atoi(e);
   if (const char* e = getenv("GAM_SP_MIN_M")) h->sp_min_m = atoi(e);
   if (const char* e = getenv("GAM_SPLITK")) h->use_splitk = atoi(e);
+  if (const char* e = getenv("GAM_GRAPH")) h->use_graph = atoi(e);
   if (const char* e = getenv("GAM_GEMM_MODE")) h->gemm_mode = (strcmp(e, "f32") == 0) ? GAM_GEMM_F32 : GAM_GEMM_F16X3;
   const gam_config& c = h->cfg;
   if (c.d_model <= 0 || c.n_heads <= 0 || c.d_model % c.n_heads != 0)
@@ -389,6 +401,10 @@ void gam_destroy(gam_handle* h) {
     if (b->p) hipFree(b->p);
   if (h->lens) hipFree(h->lens);
   for (auto& e : h->prof_events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  for (auto& g : h->graphs)
+    if (g.second.exec) hipGraphExecDestroy(g.second.exec);
+  if (h->cap_stream) hipStreamDestroy(h->cap_stream);
+  if (getenv("GAM_GRAPH_DEBUG")) fprintf(stderr, "[gam] graph replays %ld, failed captures %ld\n", h->graph_replays, h->graph_captures_failed);
   delete h;
 }
 
@@ -860,6 +876,8 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
   if (rel) {
     if (int r = ensure(h, h->pbuf, (size_t)(2 * Tv - 1) * D)) return r;
   }
+  auto run_layers = [&](hipStream_t ls) -> int {
+  hipStream_t s = ls;   // (shadows the caller's stream: the capture runs on a private one)
   GamLnArgs ln;
   memset(&ln, 0, sizeof ln);
   ln.rows = N; ln.d = D; ln.ta = Ta; ln.dk = dk; ln.eps = 1e-5f; ln.rcos = h->rot_cos; ln.rsin = h->rot_sin;
@@ -966,6 +984,46 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       }
     }
   }
+  return 0;
+  };
+
+  // Small batches: replay the layer sequence as one hipGraph (see gam_handle::use_graph).
+  bool replayed = false;
+  if (h->use_graph && !h->prof_on && nl > 0 && N < h->graph_max_rows) {
+    // every workspace the captured launches touch must exist before the capture (no allocation inside)
+    if (int r = ensure(h, h->splitk_ws, (size_t)16 * N * std::max(DFF, 2 * D) + 64)) return r;
+    const std::vector<int> key = {B, Ta, Tv, nl, h->gemm_mode, (int)sp, h->use_splitk, h->presplit};
+    gam_handle::GraphEntry& ge = h->graphs[key];
+    if (ge.gen != h->ws_generation) {   // a buffer moved since this entry was made
+      if (ge.exec) hipGraphExecDestroy(ge.exec);
+      ge = gam_handle::GraphEntry();
+      ge.gen = h->ws_generation;
+    }
+    if (ge.exec == nullptr && ge.seen == 1) {
+      hipGraph_t graph = nullptr;
+      if (h->cap_stream == nullptr && hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess)
+        h->cap_stream = nullptr;
+      if (h->cap_stream != nullptr && hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+        const int r = run_layers(h->cap_stream);     // recorded, not executed
+        const hipError_t e = hipStreamEndCapture(h->cap_stream, &graph);
+        if (r == 0 && e == hipSuccess && graph != nullptr && h->ws_generation == ge.gen &&
+            hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0) != hipSuccess)
+          ge.exec = nullptr;
+        if (graph) hipGraphDestroy(graph);
+      }
+      (void)hipGetLastError();               // a refused capture must not poison the launches below
+      if (ge.exec == nullptr) { ge.seen = 2; ++h->graph_captures_failed; }   // capture failed: never try this shape again
+    }
+    if (ge.exec != nullptr) {
+      HIPCHK(h, hipGraphLaunch(ge.exec, s));
+      replayed = true;
+      ++h->graph_replays;
+    } else if (ge.seen == 0) {
+      ge.seen = 1;
+    }
+  }
+  if (!replayed)
+    if (int r = run_layers(s)) return r;
 
   // ------------------------------ outputs ------------------------------
   {

@@ -113,7 +113,7 @@ def main():
     dev = torch.device("cuda:0")
     lines = []
     if 1 in only:
-        d = bench_py(["--batch", "1", "--seconds", "5"]); d["config"] = 1; lines.append(d)
+        d = bench_py(["--batch", "1", "--seconds", "5", "--no-profile", "--steps", "20", "--warmup", "5"]); d["config"] = 1; lines.append(d)
     if 2 in only:
         d = bench_py([]); d["config"] = 2; lines.append(d)
     if 3 in only:
