@@ -798,6 +798,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     h->lens = nullptr;
     HIPCHK(h, hipMalloc(&h->lens, (size_t)4 * B * sizeof(int)));
     h->lens_cap = B;
+    ++h->ws_generation;   // captured graphs hold the old pointer
   }
   int *len0 = h->lens, *len1 = h->lens + h->lens_cap, *len2 = h->lens + 2 * h->lens_cap, *elen = h->lens + 3 * h->lens_cap;
   if (int r = ensure(h, h->x, (size_t)N * D)) return r;
