@@ -100,16 +100,22 @@ __global__ __launch_bounds__(256) void gam_layernorm_kernel(GamLnArgs a) {
     for (int j = 0; j < GAM_LN_MAXJ; ++j) {
       const int c = (j * 64 + lane) * 4;
       if (c < a.d) {
+        // c and dk/2 are multiples of 4: the 4 elements of this lane sit in the same half of one head
         float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int cc = c + e;
-          const int i = cc % a.dk;
-          const float self = rb[cc];
-          float r;
-          if (i < half) r = self * cs[i] - rb[cc + half] * sn[i];        // x*cos + (-x2)*sin
-          else          r = self * cs[i - half] + rb[cc - half] * sn[i - half];
-          o[e] = r;
+        const int i0 = c % a.dk;
+        const bool lo_half = i0 < half;
+        const int ib = lo_half ? i0 : i0 - half;
+        const int po = lo_half ? half : -half;
+        const float4 self4 = *reinterpret_cast<const float4*>(rb + c);
+        const float4 oth4 = *reinterpret_cast<const float4*>(rb + c + po);
+        const float4 c4 = *reinterpret_cast<const float4*>(cs + ib);
+        const float4 s4 = *reinterpret_cast<const float4*>(sn + ib);
+        if (lo_half) {   // x*cos + (-x2)*sin
+          o[0] = self4.x * c4.x - oth4.x * s4.x; o[1] = self4.y * c4.y - oth4.y * s4.y;
+          o[2] = self4.z * c4.z - oth4.z * s4.z; o[3] = self4.w * c4.w - oth4.w * s4.w;
+        } else {
+          o[0] = self4.x * c4.x + oth4.x * s4.x; o[1] = self4.y * c4.y + oth4.y * s4.y;
+          o[2] = self4.z * c4.z + oth4.z * s4.z; o[3] = self4.w * c4.w + oth4.w * s4.w;
         }
         if (live) gam_store4(a.out2, (size_t)row * a.d, c, o[0], o[1], o[2], o[3], a.split2);
       }
@@ -121,6 +127,7 @@ static inline hipError_t gam_launch_layernorm(const GamLnArgs& a, int mode, hipS
   if (a.rows <= 0) return hipSuccess;
   if (a.d % 4 != 0 || a.d > GAM_LN_MAXJ * 256) return hipErrorInvalidValue;
   if ((a.split1 || a.split2) && a.d % 32 != 0) return hipErrorInvalidValue;
+  if (mode == 1 && (a.dk % 8 != 0 || a.d % a.dk != 0)) return hipErrorInvalidValue;   // rope: 4-element groups stay inside a half head
   const int grid = gam_cdiv(a.rows, 4);
   if (mode == 0) hipLaunchKernelGGL(gam_layernorm_kernel<0>, dim3(grid), dim3(256), 0, s, a);
   else if (mode == 1) hipLaunchKernelGGL(gam_layernorm_kernel<1>, dim3(grid), dim3(256), 0, s, a);

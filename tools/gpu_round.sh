@@ -1,25 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
-GAM_GRAPH_DEBUG=1 timeout 300 python - <<'PY' > gpurun_out/graph.log 2>&1
-import sys, time, torch
-sys.path.insert(0, '.')
-import gigaam_amd
-from gigaam_amd import synth
-ck = synth.make_checkpoint("v2_ctc", seed=0)
-model = gigaam_amd.model_from_checkpoint(ck, "cuda:0")
-eng = model.encoder.engine
-wav, wlen = synth.synth_audio(1, 5.0, seed=1)
-wav, wlen = wav.cuda(), wlen.cuda()
-feat, flen = eng.frontend(wav, wlen)
-for i in range(6):
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    enc, _ = eng.encode(feat, flen)
-    torch.cuda.synchronize(); print("call", i, "%.3f ms" % ((time.perf_counter() - t0) * 1e3), float(enc.abs().sum()))
-t0 = time.perf_counter()
-for i in range(50): eng.encode(feat, flen)
-torch.cuda.synchronize(); print("avg %.3f ms" % ((time.perf_counter() - t0) / 50 * 1e3))
-del model, eng
-import gc; gc.collect()
-PY
-cat gpurun_out/graph.log
+timeout 600 python -m pytest tests -m gpu -x -q -k "encoder or ctc or fullsize" > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
+timeout 300 python bench.py --cpu-utts 0 > gpurun_out/bench.log 2>gpurun_out/bench.err; tail -1 gpurun_out/bench.log | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['kernel_classes_ms_per_step'], d['roofline']['frac'], d['roofline']['achieved'])"
