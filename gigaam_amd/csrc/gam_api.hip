@@ -78,6 +78,7 @@ struct gam_handle {
 
   // frontend
   float *dft_basis = nullptr, *mel_fb = nullptr;
+  int* mel_band = nullptr;   // [2 * n_mels] non-zero bin range of each mel band
   int nf = 0, kpad = 0;
   // stem
   float *c1_w = nullptr, *c1_b = nullptr, *c2_w = nullptr, *c2_b = nullptr, *lin_w = nullptr, *lin_b = nullptr;
@@ -484,6 +485,19 @@ int gam_finalize(gam_handle* h) {
       }
     }
     UP(h->mel_fb, fb);
+    std::vector<int> band(2 * (size_t)c.n_mels, 0);
+    for (int m = 0; m < c.n_mels; ++m) {
+      int lo = nf, hi = 0;
+      for (int f = 0; f < nf; ++f)
+        if (fb[(size_t)f * c.n_mels + m] != 0.f) { lo = std::min(lo, f); hi = std::max(hi, f + 1); }
+      if (hi <= lo) lo = hi = 0;
+      band[2 * m] = lo; band[2 * m + 1] = hi;
+    }
+    void* db = nullptr;
+    if (hipMalloc(&db, band.size() * sizeof(int)) != hipSuccess) return fail(h, -2, "mel band upload failed");
+    h->owned.push_back(db);
+    if (hipMemcpy(db, band.data(), band.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail(h, -2, "mel band upload failed");
+    h->mel_band = (int*)db;
   }
 
   // ---------------- stem ----------------
@@ -763,7 +777,7 @@ int gam_frontend(gam_handle* h, const float* wav, const int64_t* wav_len, int B,
   if (int r = gemm(h, s, g, GAM_ACT_NONE, GAM_PF_FRONTEND, &h->s_dft)) return r;
   {
     GamPowMelArgs a;
-    a.spec = h->spec.p; a.fb = h->mel_fb; a.feat = feat; a.wav_len = (const long long*)wav_len; a.feat_len = (long long*)feat_len;
+    a.spec = h->spec.p; a.fb = h->mel_fb; a.band = h->mel_band; a.feat = feat; a.wav_len = (const long long*)wav_len; a.feat_len = (long long*)feat_len;
     a.B = B; a.Tfa = (int)Tfa; a.Tf = (int)Tf; a.nf = h->nf; a.n_mels = c.n_mels; a.lds = lds;
     a.hop = hop; a.win = c.win_length; a.center = c.center;
     ProfScope ps(h, s, GAM_PF_FRONTEND, (double)B * Tf * (2.0 * h->nf + c.n_mels) * 4.0);

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void gam_pad_wav_kernel(const float* wav, floa
 struct GamPowMelArgs {
   const float* spec;   // [B*Tfa, lds]: re[0..nf) | im[nf..2nf)
   const float* fb;     // [nf, n_mels]
+  const int* band;     // [2 * n_mels]: first / one-past-last frequency bin with a non-zero weight per mel band
   float* feat;         // [B, n_mels, Tf]
   const long long* wav_len;  // [B] samples (may be null -> no feat_len output)
   long long* feat_len;       // [B]
@@ -37,7 +38,7 @@ struct GamPowMelArgs {
   int hop, win, center;
 };
 
-// block: 64 frames x (n_mels <= 64) ; thread = (frame, 16-mel group)
+// block: 64 frames x (n_mels <= 64) ; thread = (frame, 16 mel bands)
 __global__ __launch_bounds__(256) void gam_powmel_kernel(GamPowMelArgs a) {
   extern __shared__ float gam_smem_pm[];   // [64][nf + 1]
   const int tid = threadIdx.x;
@@ -63,23 +64,27 @@ __global__ __launch_bounds__(256) void gam_powmel_kernel(GamPowMelArgs a) {
     gam_smem_pm[fl * pld + f] = p;
   }
   __syncthreads();
+  // mel projection: the filterbank is triangular (a bin feeds <= 2 bands), so each band sums only its
+  // own bins, in increasing bin order like the dense product (zero terms dropped).  Bands are dealt
+  // round-robin to the 4 waves (m = 4 j + wave) so the wide high-frequency bands spread evenly.
   const int fl = tid & 63, mg = tid >> 6;
   float acc[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
   const float* pw = gam_smem_pm + fl * pld;
-  for (int f = 0; f < a.nf; ++f) {
-    const float p = pw[f];
-    const float* fbr = a.fb + (size_t)f * a.n_mels + mg * 16;
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-      if (mg * 16 + j < a.n_mels) acc[j] = fmaf(p, fbr[j], acc[j]);
+  for (int j = 0; j < 16; ++j) {
+    const int m = 4 * j + mg;
+    float s = 0.f;
+    if (m < a.n_mels) {
+      const int f0 = a.band[2 * m], f1 = a.band[2 * m + 1];   // wave-uniform
+      for (int f = f0; f < f1; ++f) s = fmaf(pw[f], a.fb[(size_t)f * a.n_mels + m], s);
+    }
+    acc[j] = s;
   }
   const int t = t0 + fl;
   if (t < a.Tf) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int m = mg * 16 + j;
+      const int m = 4 * j + mg;
       if (m < a.n_mels) {
         float v = acc[j];
         v = fminf(fmaxf(v, 1e-9f), 1e9f);
