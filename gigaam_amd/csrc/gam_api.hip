@@ -111,6 +111,7 @@ struct gam_handle {
   struct GraphEntry { uint64_t gen = 0; int seen = 0; hipGraphExec_t exec = nullptr; };
   std::map<std::vector<int>, GraphEntry> graphs;
   long graph_replays = 0, graph_captures_failed = 0;
+  int graph_count = 0;          // instantiated graphs alive (capped at 32 shapes)
   hipStream_t cap_stream = nullptr;   // private stream for captures (the caller's may be the legacy default stream)
   int* lens = nullptr;  // 4 * maxB ints: len0, len1, len2, enc_len
   int lens_cap = 0;
@@ -1010,10 +1011,11 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     const std::vector<int> key = {B, Ta, Tv, nl, h->gemm_mode, (int)sp, h->use_splitk, h->presplit};
     gam_handle::GraphEntry& ge = h->graphs[key];
     if (ge.gen != h->ws_generation) {   // a buffer moved since this entry was made
-      if (ge.exec) hipGraphExecDestroy(ge.exec);
+      if (ge.exec) { hipGraphExecDestroy(ge.exec); --h->graph_count; }
       ge = gam_handle::GraphEntry();
       ge.gen = h->ws_generation;
     }
+    if (ge.exec == nullptr && ge.seen == 1 && h->graph_count >= 32) ge.seen = 2;   // cache full: plain launches
     if (ge.exec == nullptr && ge.seen == 1) {
       hipGraph_t graph = nullptr;
       if (h->cap_stream == nullptr && hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking) != hipSuccess)
@@ -1027,7 +1029,8 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
         if (graph) hipGraphDestroy(graph);
       }
       (void)hipGetLastError();               // a refused capture must not poison the launches below
-      if (ge.exec == nullptr) { ge.seen = 2; ++h->graph_captures_failed; }   // capture failed: never try this shape again
+      if (ge.exec == nullptr) { ge.seen = 2; ++h->graph_captures_failed; }
+      else ++h->graph_count;   // capture failed: never try this shape again
     }
     if (ge.exec != nullptr) {
       HIPCHK(h, hipGraphLaunch(ge.exec, s));
