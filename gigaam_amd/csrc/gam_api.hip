@@ -97,7 +97,6 @@ struct gam_handle {
 
   // workspace (grow-only)
   DevBuf wavp, spec, img, c2, xin, y1, x, y, yr, hbuf, qk, vbuf, ctx, ubuf, zbuf, tok, logits, encp, pbuf, aplanes;
-  int presplit = 0;   // GAM_PRESPLIT=1: split A in a pre-pass (experiment)
   int use_sp = 1;     // large-M GEMMs on the LDS-DMA sp32 kernel (GAM_SP=0 disables)
   int sp_min_m = GAM_SP_MIN_M;   // GAM_SP_MIN_M overrides (tests force the sp path at small sizes)
   DevBuf op_planes, op_sp, splitk_ws;   // gam_op_gemm operand planes; split-K partial sums
@@ -314,16 +313,6 @@ int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls
   }
   if (f16) {
     a.Whi = w16->hi; a.Wlo = w16->lo; a.wscale_inv = w16->inv;
-    if (h->presplit && S == 1 && a.Ahi == nullptr && a.a_mode == 0) {
-      const size_t count = ((size_t)(a.M - 1) * (size_t)a.lda + (size_t)a.K + 7) / 8 * 8;
-      if (int r = ensure(h, h->aplanes, count + 64)) return r;
-      _Float16* hi = (_Float16*)h->aplanes.p;
-      _Float16* lo = hi + count + 8;
-      const size_t n4 = count / 4;
-      const int grid = (int)std::min<size_t>((n4 + 255) / 256, 256 * 16);
-      hipLaunchKernelGGL(gam_split_kernel, dim3(grid), dim3(256), 0, s, a.A, hi, lo, n4);
-      a.Ahi = hi; a.Alo = lo;
-    }
     e = gam_launch_gemm16(a, act, s);
   } else {
     e = gam_launch_gemm(a, act, s);
@@ -371,7 +360,6 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   h->cfg = *cfg;
   h->device = device_id;
   *out = h;
-  if (const char* e = getenv("GAM_PRESPLIT")) h->presplit = atoi(e);
   if (const char* e = getenv("GAM_SP")) h->use_sp = atoi(e);
   if (const char* e = getenv("GAM_SP_MIN_M")) h->sp_min_m = atoi(e);
   if (const char* e = getenv("GAM_SPLITK")) h->use_splitk = atoi(e);
@@ -1008,7 +996,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
   if (h->use_graph && !h->prof_on && nl > 0 && N < h->graph_max_rows) {
     // every workspace the captured launches touch must exist before the capture (no allocation inside)
     if (int r = ensure(h, h->splitk_ws, (size_t)16 * N * std::max(DFF, 2 * D) + 64)) return r;
-    const std::vector<int> key = {B, Ta, Tv, nl, h->gemm_mode, (int)sp, h->use_splitk, h->presplit};
+    const std::vector<int> key = {B, Ta, Tv, nl, h->gemm_mode, (int)sp, h->use_splitk};
     gam_handle::GraphEntry& ge = h->graphs[key];
     if (ge.gen != h->ws_generation) {   // a buffer moved since this entry was made
       if (ge.exec) { hipGraphExecDestroy(ge.exec); --h->graph_count; }

@@ -53,10 +53,6 @@ struct GamGemmArgs {
   // split-fp16 operand planes of W (gam_gemm16.h): W * 2^wshift = Whi + Wlo (+ ~2^-22 |W|)
   const _Float16* Whi;
   const _Float16* Wlo;
-  // optional split planes of A (same element indexing as the fp32 A, lda in elements):
-  // produced by gam_split_kernel or directly by the producing kernel
-  const _Float16* Ahi;
-  const _Float16* Alo;
   // both operands in the sp32 layout of gam_gemm_sp.h (row pitch = lda / K elements, 4 B each)
   const _Float16* Asp;
   const _Float16* Wsp;

@@ -30,18 +30,17 @@ struct GamGemm16Cfg {
   static constexpr int STAGE = 2 * (APLANE + WPLANE);    // halfs per LDS stage (4 planes)
   static constexpr int SMEM = STAGE * 2;                 // bytes per stage
   static constexpr int A_F4 = BM * BK / 4 / NT;          // float4 loads of A per thread per k-tile
-  static constexpr int A_CH = BM * BK / 8 / NT;          // 16-byte chunks per thread per A plane (plane input)
   static constexpr int W_CH = 128 * BK / 8 / NT;         // 16-byte chunks per thread per W plane per k-tile
 };
 
 
-template <int ACT, int BK, bool AP, int BM, bool PIPE>
-__global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : (BK == 32 ? 3 : 2))) void gam_gemm_f16x3_kernel(GamGemmArgs g) {
+template <int ACT, int BM, bool PIPE>
+__global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : 3)) void gam_gemm_f16x3_kernel(GamGemmArgs g) {
+  constexpr int BK = 32;
   extern __shared__ __attribute__((aligned(16))) _Float16 gam_smem16[];
   if (g.splitk > 1) {
     const size_t ko = (size_t)blockIdx.y * (size_t)g.K;
     g.A += ko; g.Whi += ko; g.Wlo += ko;
-    if constexpr (AP) { g.Ahi += ko; g.Alo += ko; }
   }
   using Cfg = GamGemm16Cfg<BK, BM>;
   constexpr int BN = 128, LD = Cfg::LD, NT = Cfg::NT;
@@ -66,9 +65,8 @@ __global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : (BK == 32 ? 3 :
 
   // ---- A staging: float4 index f = tid + 256*i over [128 rows][BK/4];  W staging: 16 B chunk
   //      c = tid + 256*i over [128 rows][BK/8] per plane
-  // AP = true: A arrives as fp16 planes (16-byte chunks, like W); AP = false: fp32, split here
-  constexpr int AF = AP ? Cfg::A_CH : Cfg::A_F4, WC = Cfg::W_CH, F4R = AP ? BK / 8 : BK / 4, CHR = BK / 8;
-  constexpr int AEL = AP ? 8 : 4;   // elements per A staging item
+  constexpr int AF = Cfg::A_F4, WC = Cfg::W_CH, F4R = BK / 4, CHR = BK / 8;
+  constexpr int AEL = 4;   // elements per A staging item (fp32 A, split while it is staged)
   size_t a_off[AF];
   int a_lds[AF];
 #pragma unroll
@@ -103,8 +101,7 @@ __global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : (BK == 32 ? 3 :
   for (int r = 0; r < 16; ++r) { acc00[r] = 0.f; acc01[r] = 0.f; acc10[r] = 0.f; acc11[r] = 0.f; }
 
   const int nk = g.K / BK;
-  f32x4 va[AP ? 1 : AF];
-  gam_u32x4 vah[AP ? AF : 1], val[AP ? AF : 1];
+  f32x4 va[AF];
   gam_u32x4 vh[WC], vl[WC];
 
   auto gload = [&](int kt) {
@@ -115,16 +112,8 @@ __global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : (BK == 32 ? 3 :
       const int kh = tap / 3, kw = tap - kh * 3;
       ka = ((size_t)kh * g.conv_fp + kw) * (size_t)g.conv_c + c0;
     }
-    if constexpr (AP) {
 #pragma unroll
-      for (int i = 0; i < AF; ++i) {
-        vah[i] = *reinterpret_cast<const gam_u32x4*>(g.Ahi + a_off[i] + ka);
-        val[i] = *reinterpret_cast<const gam_u32x4*>(g.Alo + a_off[i] + ka);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < AF; ++i) va[i] = *reinterpret_cast<const f32x4*>(g.A + a_off[i] + ka);
-    }
+    for (int i = 0; i < AF; ++i) va[i] = *reinterpret_cast<const f32x4*>(g.A + a_off[i] + ka);
 #pragma unroll
     for (int i = 0; i < WC; ++i) {
       vh[i] = *reinterpret_cast<const gam_u32x4*>(g.Whi + w_off[i] + k0);
@@ -136,20 +125,12 @@ __global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : (BK == 32 ? 3 :
     _Float16* al = Alo + buf * Cfg::STAGE;
     _Float16* wh = Whi + buf * Cfg::STAGE;
     _Float16* wl = Wlo + buf * Cfg::STAGE;
-    if constexpr (AP) {
 #pragma unroll
-      for (int i = 0; i < AF; ++i) {
-        *reinterpret_cast<gam_u32x4*>(ah + a_lds[i]) = vah[i];
-        *reinterpret_cast<gam_u32x4*>(al + a_lds[i]) = val[i];
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < AF; ++i) {
-        gam_half4 hi, lo;
-        gam_split4(va[i], hi, lo);
-        *reinterpret_cast<gam_half4*>(ah + a_lds[i]) = hi;
-        *reinterpret_cast<gam_half4*>(al + a_lds[i]) = lo;
-      }
+    for (int i = 0; i < AF; ++i) {
+      gam_half4 hi, lo;
+      gam_split4(va[i], hi, lo);
+      *reinterpret_cast<gam_half4*>(ah + a_lds[i]) = hi;
+      *reinterpret_cast<gam_half4*>(al + a_lds[i]) = lo;
     }
 #pragma unroll
     for (int i = 0; i < WC; ++i) {
@@ -183,7 +164,6 @@ __global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : (BK == 32 ? 3 :
     // global_load issue slots fall into the shadow of MFMAs in flight.  (With separate load /
     // store / multiply phases the co-resident workgroups run phase-aligned and the three costs
     // add up: measured 614 + 369 + 163 us at K = 12288.)
-    static_assert(!AP && BK == 32, "pipelined variant: fp32 A, BK = 32");
     auto item = [&](auto st, auto ld, int j, int sbuf, size_t ka, int k0) {
       // staging item j: 0..AF-1 = A float4 j ; AF..AF+2*WC-1 = W chunk (hi/lo interleaved)
       if (j < AF) {
@@ -264,11 +244,11 @@ __global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : (BK == 32 ? 3 :
   gam_gemm_epilogue<ACT>(g, acc00, acc01, acc10, acc11, m0, n0, wm, wn, lane, g.wscale_inv);
 }
 
-template <int ACT, int BK, bool AP, int BM = 128, bool PIPE = false>
+template <int ACT, int BM = 128, bool PIPE = false>
 static inline void gam_launch_gemm16_t(const GamGemmArgs& a, int grid, hipStream_t stream) {
   static bool attr_done = false;
-  constexpr int smem = GamGemm16Cfg<BK, BM>::SMEM * (PIPE ? 2 : 1);
-  auto kern = gam_gemm_f16x3_kernel<ACT, BK, AP, BM, PIPE>;
+  constexpr int smem = GamGemm16Cfg<32, BM>::SMEM * (PIPE ? 2 : 1);
+  auto kern = gam_gemm_f16x3_kernel<ACT, BM, PIPE>;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     attr_done = true;
@@ -289,15 +269,6 @@ __global__ __launch_bounds__(256) void gam_split_kernel(const float* __restrict_
   }
 }
 
-static inline int gam_gemm16_bk() {
-  static int v = 0;
-  if (v == 0) {
-    const char* e = getenv("GAM_F16_BK");
-    v = (e && e[0] == '6') ? 64 : 32;
-  }
-  return v;
-}
-
 static inline hipError_t gam_launch_gemm16(const GamGemmArgs& a_in, int act, hipStream_t stream) {
   GamGemmArgs a = a_in;
   if (a.ldw == 0) a.ldw = a.K;
@@ -308,21 +279,19 @@ static inline hipError_t gam_launch_gemm16(const GamGemmArgs& a_in, int act, hip
   static int bm256_min = -1;
   if (bm256_min < 0) { const char* e = getenv("GAM_BM256_MIN"); bm256_min = e ? atoi(e) : 1000; }
   const int t256 = gam_cdiv(a.M, 256) * gam_cdiv(a.N, 128);
-  const bool big = a.Ahi == nullptr && t256 >= bm256_min && a.K % 32 == 0;
+  const bool big = t256 >= bm256_min && a.K % 32 == 0;
   if (big) {
     a.ntiles = t256;
     switch (act) {
-      case GAM_ACT_SILU: gam_launch_gemm16_t<GAM_ACT_SILU, 32, false, 256, false>(a, t256, stream); break;
-      case GAM_ACT_RELU: gam_launch_gemm16_t<GAM_ACT_RELU, 32, false, 256, false>(a, t256, stream); break;
-      default: gam_launch_gemm16_t<GAM_ACT_NONE, 32, false, 256, false>(a, t256, stream); break;
+      case GAM_ACT_SILU: gam_launch_gemm16_t<GAM_ACT_SILU, 256, false>(a, t256, stream); break;
+      case GAM_ACT_RELU: gam_launch_gemm16_t<GAM_ACT_RELU, 256, false>(a, t256, stream); break;
+      default: gam_launch_gemm16_t<GAM_ACT_NONE, 256, false>(a, t256, stream); break;
     }
     return hipGetLastError();
   }
   a.ntiles = gam_cdiv(a.M, 128) * gam_cdiv(a.N, 128);
   const int grid = a.ntiles;
-  const bool bk64 = gam_gemm16_bk() == 64 && a.K % 64 == 0 && (a.a_mode == 0 || a.conv_c % 64 == 0);
-  if (!bk64 && a.K % 32 != 0) return hipErrorInvalidValue;
-  const bool ap = a.Ahi != nullptr;
+  if (a.K % 32 != 0) return hipErrorInvalidValue;
   // Few tiles (< 2 per CU: short utterances, single clips): occupancy cannot hide the staging
   // phases, the in-wave pipelined variant wins (M = 2008: 62 -> 72 TF); many tiles: three
   // phase-separated workgroups per CU win (K = 3072: 285 vs 275 TF).  GAM_PIPE=0/1 forces one.
@@ -330,11 +299,8 @@ static inline hipError_t gam_launch_gemm16(const GamGemmArgs& a_in, int act, hip
   if (pipe_env == -2) { const char* e = getenv("GAM_PIPE"); pipe_env = e ? atoi(e) : -1; }
   const bool pipe = pipe_env >= 0 ? pipe_env != 0 : grid <= 512;
 #define GAM_L16(ACTV)                                                                     \
-  if (bk64) { if (ap) gam_launch_gemm16_t<ACTV, 64, true>(a, grid, stream);               \
-              else gam_launch_gemm16_t<ACTV, 64, false>(a, grid, stream); }               \
-  else if (ap) gam_launch_gemm16_t<ACTV, 32, true>(a, grid, stream);                      \
-  else if (pipe) gam_launch_gemm16_t<ACTV, 32, false, 128, true>(a, grid, stream);        \
-  else gam_launch_gemm16_t<ACTV, 32, false, 128, false>(a, grid, stream);
+  if (pipe) gam_launch_gemm16_t<ACTV, 128, true>(a, grid, stream);                        \
+  else gam_launch_gemm16_t<ACTV, 128, false>(a, grid, stream);
   switch (act) {
     case GAM_ACT_SILU: GAM_L16(GAM_ACT_SILU); break;
     case GAM_ACT_RELU: GAM_L16(GAM_ACT_RELU); break;

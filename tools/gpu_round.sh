@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q -k "v3 or fullsize" > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
-timeout 300 python bench.py --model v3_ctc --cpu-utts 4 > gpurun_out/bench.log 2>gpurun_out/bench.err; tail -1 gpurun_out/bench.log | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['kernel_classes_ms_per_step'], d['cpu_baseline'].get('gpu_ids_identical'))"
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu.log 2>&1; tail -3 gpurun_out/pytest_gpu.log
+GAM_SP=0 timeout 300 python bench.py --cpu-utts 4 --steps 3 --warmup 1 > gpurun_out/bench.log 2>gpurun_out/bench.err; tail -1 gpurun_out/bench.log | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('GAM_SP=0', d['value'], d['ms_per_step'], d['cpu_baseline'].get('gpu_ids_identical'))"
