@@ -151,6 +151,16 @@ __global__ __launch_bounds__(256) void gam_rnnt_greedy_kernel(GamRnntArgs a) {
     for (int i = tid; i < V * JH; i += 256) wout_l[(i / JH) * WLD + (i % JH)] = a.wout[i];
   __syncthreads();
 
+  // (frame, k) of this thread's window elements, fixed for the whole decode (index clamped: every load
+  // is unconditional)
+  int zfk[GAM_RNNT_WIN * GAM_RNNT_MAXH / 256];
+#pragma unroll
+  for (int u = 0; u < GAM_RNNT_WIN * GAM_RNNT_MAXH / 256; ++u) {
+    int idx = tid + 256 * u;
+    idx = idx < GAM_RNNT_WIN * JH ? idx : GAM_RNNT_WIN * JH - 1;
+    const int f = idx / JH;
+    zfk[u] = (f << 16) | (idx - f * JH);
+  }
   int label = V;       // gate_tab row V: zero embedding (predict(None, None), decoder.py:97-100)
   int n_out = 0, n_dump = 0;
   int t = 0, sym = 0;  // current frame, symbols already emitted on it
@@ -225,10 +235,22 @@ __global__ __launch_bounds__(256) void gam_rnnt_greedy_kernel(GamRnntArgs a) {
 
     // ---- joint of frames t .. t+W-1 with the current predictor state ----
     const int W = len - t < GAM_RNNT_WIN ? len - t : GAM_RNNT_WIN;
-    for (int idx = tid; idx < GAM_RNNT_WIN * JH; idx += 256) {
-      const int f = idx / JH, k = idx - f * JH;
-      const int tt = t + (f < W ? f : W - 1);
-      zw[f * ZLD + k] = fmaxf(a.encp[((size_t)b * a.Tp + tt) * JH + k] + pp[k], 0.f);
+    {
+      // all encoder-projection loads of the window in flight together (a plain strided loop keeps one
+      // load outstanding per thread: 20 dependent L2 round trips per window)
+      constexpr int NZ = GAM_RNNT_WIN * GAM_RNNT_MAXH / 256;
+      float ze[NZ];
+#pragma unroll
+      for (int u = 0; u < NZ; ++u) {
+        const int f = zfk[u] >> 16, k = zfk[u] & 0xffff;
+        const int tt = t + (f < W ? f : W - 1);
+        ze[u] = a.encp[((size_t)b * a.Tp + tt) * JH + k];
+      }
+#pragma unroll
+      for (int u = 0; u < NZ; ++u) {
+        const int f = zfk[u] >> 16, k = zfk[u] & 0xffff;
+        if (tid + 256 * u < GAM_RNNT_WIN * JH) zw[f * ZLD + k] = fmaxf(ze[u] + pp[k], 0.f);
+      }
     }
     __syncthreads();
     // logits[f][v] = bout[v] + sum_k z[f][k] * wout[v][k]: one 16x16 MFMA tile per 16 classes
