@@ -1,5 +1,5 @@
-// gam_gemm_sp.h -- the large-M split-fp16 GEMM: 64*MT x 256 block tiles fed entirely by
-// LDS-DMA (global_load_lds_dwordx4), two 64 KB LDS stages, one barrier per k-tile.
+// gam_gemm_sp.h -- the large-M split-fp16 GEMM: (64 MT) x (64 NW) block tiles fed entirely by
+// LDS-DMA (global_load_lds_dwordx4), two LDS stages (<= 64 KB each), one barrier per k-tile.
 //
 // Same arithmetic as gam_gemm16.h (a.w ~= (a_hi.w_hi + a_hi.w_lo + a_lo.w_hi) 2^-s on
 // v_mfma_f32_32x32x16_f16, fp32 accumulate) but both operands arrive already split, in the
@@ -19,10 +19,11 @@
 // XOR and every 16-lane service group of a ds_read_b128 (rows distinct mod 16) covers all 16 slots
 // of the 256-byte bank row exactly once: conflict-free without padding.
 //
-// 8 waves = 2 (M) x 4 (N); a wave owns (32*MT) x 64 outputs = MT x 2 MFMA tiles, 3 MFMAs per
-// tile per k16-step.  Bytes moved per FLOP are half those of the 128x128 kernel and the k-tile of
-// the next iteration lands while the current one is multiplied.  MT in {2,3,4} (BM = 128/192/256)
-// is picked per launch to minimise the tail of the last round of tiles.
+// 2 (M) x NW (N) waves; a wave owns (32 MT) x 64 outputs = MT x 2 MFMA tiles, 3 MFMAs per tile per
+// k16-step.  At NW = 4 (256-wide tiles, one workgroup per CU) the bytes moved per FLOP are half
+// those of the 128x128 kernel; the k-tile after next lands while the current one is multiplied.
+// MT in {2,3,4} and NW in {2,4} are picked per launch (gam_gemm_sp_pick) to minimise the tail of the
+// last round of tiles.
 #pragma once
 #include "gam_gemm16.h"
 
@@ -35,15 +36,6 @@
 #define GAM_SP_DBG(g) (GAM_SP_INSTRUMENT ? (g).dbg : 0)
 
 #define GAM_SP_MIN_M 2048   // below this the 128x128 kernels fill the chip better
-
-// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
-template <int N, int I = 0, class F>
-__device__ __forceinline__ void gam_static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    gam_static_for<N, I + 1>(f);
-  }
-}
 
 template <int MT, int NW>
 struct GamGemmSpCfg {
