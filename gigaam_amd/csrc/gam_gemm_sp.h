@@ -51,45 +51,6 @@ struct GamGemmSpCfg {
   static constexpr int NWI = BN / 8 / NWAVES;   // W DMA pieces per wave per k-tile
 };
 
-// one 32x32 accumulator tile -> C (fp32, or sp32 halves when g.c_split)
-template <int ACT>
-__device__ __forceinline__ void gam_gemm_epi_tile(const GamGemmArgs& g, const f32x16& acc, int mrow0, int ncol0,
-                                                  int lane, float accscale) {
-  const int col = ncol0 + (lane & 31);
-  const int lrow4 = 4 * (lane >> 5);
-  const bool colok = col < g.N;
-  const float bv = (g.bias != nullptr && colok) ? g.bias[col] : 0.0f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = mrow0 + (r & 3) + 8 * (r >> 2) + lrow4;
-    if (row >= g.M || !colok) continue;
-    bool masked = false;
-    long orow = row;
-    if (g.lens != nullptr || g.remap) {
-      const int bb = row / g.rpb, tt = row - bb * g.rpb;
-      if (g.lens != nullptr) masked = (tt / g.fdiv) >= g.lens[bb];
-      if (g.remap) {
-        if (tt >= g.rows_valid) continue;
-        orow = (long)bb * g.out_rpb + tt + g.out_shift;
-      }
-    }
-    float v = acc[r] * accscale + bv;
-    if (ACT == GAM_ACT_SILU) v = gam_silu(v);
-    if (ACT == GAM_ACT_RELU) v = fmaxf(v, 0.0f);
-    if (masked) v = 0.0f;
-    v *= g.alpha;
-    if (g.R != nullptr) v += g.R[orow * g.ldr + col];
-    if (g.c_split) {
-      _Float16* cp = reinterpret_cast<_Float16*>(g.C) + orow * (2 * g.ldc) + (col >> 5) * 64 + (col & 31);
-      const _Float16 h = (_Float16)v;
-      cp[0] = h;
-      cp[32] = (_Float16)(v - (float)h);
-    } else {
-      g.C[orow * g.ldc + col] = v;
-    }
-  }
-}
-
 template <int ACT, int MT, int NW>
 __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(GamGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gam_smem_sp[];
