@@ -20,7 +20,9 @@ Pinning status
   pyproject.toml:30-33) is not installed and not under /root/reference, and
   the reference's tests that cover it need network + checkpoints.  The
   restatement follows torchaudio's published contract on
-  ``torch.stft`` and is checked by analytic known-answer tests only.
+  ``torch.stft`` and is checked by analytic known-answer tests and against an
+  independent fp64 scipy.fft implementation (tests/test_oracle_golden.py) --
+  neither of which is the reference itself.
 """
 from __future__ import annotations
 

@@ -92,3 +92,29 @@ def test_frontend_known_answers():
                            torch.from_numpy(synth.hann_window_periodic(320)),
                            torch.from_numpy(synth.mel_filterbank_htk(161, 64, 16000)))
     assert feat.shape[2] == (16000 - 320) // 160 + 1 == int(flen)
+
+
+def test_frontend_against_independent_scipy_stft():
+    """a1 has no reference-produced golden (torchaudio is absent here): besides the analytic checks above,
+    the restatement is compared with an INDEPENDENT fp64 implementation built on scipy.signal (framing by
+    hand, reflect padding, periodic Hann, rfft) -- a different code path from torch.stft."""
+    import scipy.fft
+    from gigaam_amd import synth
+    for name, n_fft, center in (("v2_ctc", 400, True), ("v3_ctc", 320, False)):
+        cfg = synth.model_cfg(name)["preprocessor"]
+        win = synth.hann_window_periodic(n_fft)
+        fbank = synth.mel_filterbank_htk(n_fft // 2 + 1, 64, 16000)
+        wav, lens = synth.synth_audio(2, 1.5, seed=77, lengths=[24000, 17000])
+        feat, flen = O.log_mel(wav, lens, cfg, torch.from_numpy(win), torch.from_numpy(fbank))
+        x = wav.numpy().astype(np.float64)
+        if center:
+            x = np.pad(x, ((0, 0), (n_fft // 2, n_fft // 2)), mode="reflect")
+        n_frames = (x.shape[1] - n_fft) // 160 + 1
+        frames = np.stack([x[:, i * 160: i * 160 + n_fft] for i in range(n_frames)], axis=1) * win.astype(np.float64)
+        power = np.abs(scipy.fft.rfft(frames, axis=-1)) ** 2                       # [B, T, n_freq]
+        ref = np.log(np.clip(power @ fbank.astype(np.float64), 1e-9, 1e9)).transpose(0, 2, 1)
+        assert feat.shape == ref.shape and flen.tolist() == [(l // 160 + 1) if center else ((l - n_fft) // 160 + 1) for l in lens.tolist()]
+        ref_t = torch.from_numpy(ref)
+        strong = ref_t >= ref_t.max(dim=1, keepdim=True).values - 60.0 * 0.2302585   # see tests/common.py
+        d = (feat.double() - ref_t).abs()
+        assert float((d * strong).max()) < 5e-4 and float((d * ~strong).max()) < 2e-2
