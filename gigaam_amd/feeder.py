@@ -19,6 +19,22 @@ def collate_lengths(segments: Sequence[Tensor]) -> Tuple[int, Tensor]:
     return int(lens.max()) if len(segments) else 0, lens
 
 
+def collate(segments: Sequence[Tensor], out: Tensor = None) -> Tuple[Tensor, Tensor]:
+    """``AudioDataset.collate`` layout (reference gigaam/utils.py:371-380): ``(batch f32 [B, max_len]
+    zero-padded, lengths i64 [B])``.  ``out`` (optional) is a flat buffer with at least B*max_len elements --
+    the feeder passes its pinned staging buffer so the batch is assembled in place."""
+    lmax, lens = collate_lengths(segments)
+    b = len(segments)
+    if out is None:
+        batch = torch.zeros((b, lmax), dtype=segments[0].dtype if b else torch.float32)
+    else:
+        batch = out[: b * lmax].view(b, lmax)
+        batch.zero_()
+    for j, c in enumerate(segments):
+        batch[j, : c.shape[-1]] = c.reshape(-1)
+    return batch, lens
+
+
 def batches(segments: Sequence[Tensor], batch_size: int) -> Iterator[List[Tensor]]:
     for i in range(0, len(segments), batch_size):
         yield list(segments[i:i + batch_size])
@@ -40,13 +56,10 @@ class BatchFeeder:
 
     def _stage(self, slot: int, chunk: List[Tensor]):
         b = len(chunk)
-        lmax, lens = collate_lengths(chunk)
         if self._ready[slot] is not None:       # the copy issued two batches ago must have left this buffer
             self._ready[slot].synchronize()
-        host = self._pin[slot][: b * lmax].view(b, lmax)      # contiguous pinned view of exactly this batch
-        host.zero_()
-        for j, c in enumerate(chunk):
-            host[j, : c.shape[-1]] = c
+        host, lens = collate(chunk, out=self._pin[slot])      # contiguous pinned view of exactly this batch
+        lmax = host.shape[1]
         self._pin_len[slot][:b] = lens
         with torch.cuda.stream(self._copy_stream):
             # contiguous device tensors of exactly this batch's shape

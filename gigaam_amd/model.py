@@ -194,6 +194,18 @@ class GigaAMASR(GigaAM):
 
         if kwargs.get("vad") == "energy":   # stand-in detector on the HIP frontend (NOT pyannote)
             kwargs["vad"] = EnergyVAD(self.preprocessor)
+        elif kwargs.get("vad") is None and kwargs.get("speech_regions") is None:
+            # reference default: pyannote (model.py:212-216 -> vad_utils.py:100-101).  Without that optional
+            # third-party package the call still works, on the labelled stand-in, and says so.
+            try:
+                import pyannote.audio  # noqa: F401
+            except ImportError:
+                import warnings
+                warnings.warn("pyannote.audio is not installed: transcribe_longform() segments with gigaam_amd's "
+                              "EnergyVAD stand-in instead of the reference's pyannote/segmentation-3.0 pipeline "
+                              "(chunk boundaries will differ); pass speech_regions= or vad= to control segmentation",
+                              RuntimeWarning, stacklevel=2)
+                kwargs["vad"] = EnergyVAD(self.preprocessor)
         segments, boundaries = segment_audio_file(wav_file, SAMPLE_RATE, device=self._device, **kwargs)
         if not segments:
             return LongformTranscriptionResult(segments=[])

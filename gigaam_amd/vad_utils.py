@@ -60,12 +60,46 @@ def segment_audio_file(wav_file: str, sr: int, device=None,
                        **pack_kwargs) -> Tuple[List[Tensor], List[Tuple[float, float]]]:
     audio = load_audio(wav_file, sr)
     if speech_regions is None:
-        if vad is None:
-            raise RuntimeError("no VAD available: pass speech_regions=[(start,end),...] or vad=callable "
-                               "(the reference's pyannote pipeline is not part of this package)")
-        speech_regions = vad(audio, sr)
+        if vad is None:   # the reference's default: pyannote's VAD pipeline on the file (vad_utils.py:100-101)
+            speech_regions = pyannote_regions(wav_file, device)
+        else:
+            speech_regions = vad(audio, sr)
     bounds = pack_regions(speech_regions, audio.shape[0] / sr, **pack_kwargs)
     return [audio[int(s * sr): int(e * sr)] for s, e in bounds], bounds
+
+
+_PIPELINE = None
+
+
+def pyannote_regions(wav_file: str, device=None, model_id: str = "pyannote/segmentation-3.0") -> List[Tuple[float, float]]:
+    """The reference's segmentation source (gigaam/vad_utils.py:17-77,100-101): pyannote's
+    VoiceActivityDetection pipeline over ``pyannote/segmentation-3.0`` (local snapshot, else HF_TOKEN
+    download), ``min_duration_on = min_duration_off = 0``, loaded once.  pyannote is an optional third-party
+    dependency (the reference lists it under its ``longform`` extra); when it is not importable this raises
+    ImportError and the caller decides (GigaAMASR.transcribe_longform falls back to EnergyVAD, loudly)."""
+    global _PIPELINE
+    import os
+
+    from huggingface_hub import snapshot_download
+    from pyannote.audio import Model
+    from pyannote.audio.core.task import Problem, Resolution, Specifications
+    from pyannote.audio.pipelines import VoiceActivityDetection
+    from torch.torch_version import TorchVersion
+
+    if _PIPELINE is None:
+        try:
+            local = snapshot_download(repo_id=model_id, local_files_only=True)
+        except Exception:
+            token = os.getenv("HF_TOKEN")
+            if not token:
+                raise RuntimeError(f"Model {model_id} was not found locally, and no HF_TOKEN was provided to download it.")
+            local = snapshot_download(repo_id=model_id, token=token)
+        with torch.serialization.safe_globals([TorchVersion, Problem, Specifications, Resolution]):
+            seg_model = Model.from_pretrained(local)
+        _PIPELINE = VoiceActivityDetection(segmentation=seg_model)
+        _PIPELINE.instantiate({"min_duration_on": 0.0, "min_duration_off": 0.0})
+    pipe = _PIPELINE.to(torch.device(device) if device is not None else torch.device("cpu"))
+    return [(float(s.start), float(s.end)) for s in pipe(wav_file).get_timeline().support()]
 
 
 class EnergyVAD:

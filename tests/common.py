@@ -12,19 +12,8 @@ if ROOT not in sys.path:
 from gigaam_amd import synth  # noqa: E402
 from oracle import gigaam_oracle as O  # noqa: E402
 
-# must match tests/golden/make_golden.py
-CASES = {
-    "v2_ctc_l2": ("v2_ctc", 1, 2, (3, 4.0, 11, [64000, 50000, 33333])),
-    "v2_ctc_l2_b1": ("v2_ctc", 1, 2, (1, 2.5, 12, None)),
-    "v2_rnnt_l2": ("v2_rnnt", 1, 2, (3, 4.0, 13, [64000, 41234, 57000])),
-    "v3_ctc_l2": ("v3_ctc", 1, 2, (3, 4.0, 14, [64000, 50000, 33333])),
-    "v3_e2e_rnnt_l2": ("v3_e2e_rnnt", 1, 2, (2, 3.0, 15, [48000, 30011])),
-    "v1_ctc_l2": ("v1_ctc", 1, 2, (3, 3.0, 16, [48000, 40000, 20000])),
-    "v2_ctc_l2_short": ("v2_ctc", 1, 2, (2, 0.3125, 17, [5000, 3200])),
-    "v3_e2e_ctc_l2": ("v3_e2e_ctc", 1, 2, (2, 3.0, 19, [48000, 35000])),
-    "v1_rnnt_l2": ("v1_rnnt", 1, 2, (2, 2.5, 20, [40000, 26000])),
-}
-EMO_CASE = ("emo", 1, 2, (2, 3.0, 18, [48000, 36000]))   # tests/golden/emo_l2.npz
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from cases import CASES, EMO_CASE, RNNT_MIN_MARGIN, make_case_checkpoint  # noqa: E402  (shared with make_golden.py)
 
 # tolerances (fp32 vs fp32, different summation orders)
 TOL_FEAT = 2e-3      # log-mel, natural-log units
@@ -53,12 +42,35 @@ def tol_pre(ref):
 TOL_LOGP = 1e-3      # CTC / RNN-T log-probs: BASELINE.json north_star "within 1e-3 fp32"
 
 
+def report(name, **values):
+    """Append measured errors to $GAM_TEST_REPORT (a .jsonl) so tolerances can be read beside what was measured."""
+    path = os.environ.get("GAM_TEST_REPORT")
+    if path:
+        import json
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(test=name, **values)) + "\n")
+
+
+def frontend_fixture(name):
+    """torchaudio-made log-mel of a case (tests/golden/make_frontend_golden.py), or None: the build container has no
+    torchaudio, so until someone runs that script elsewhere row a1 is parity-unpinned."""
+    path = os.path.join(ROOT, "tests", "golden", f"frontend_{name}.npz")
+    return dict(np.load(path)) if os.path.exists(path) else None
+
+
 def load_case(name):
-    model, seed, nl, (b, secs, aseed, lens) = CASES[name]
-    ck = synth.make_checkpoint(model, seed=seed, n_layers=nl)
-    wav, wlen = synth.synth_audio(b, secs, seed=aseed, lengths=lens)
+    ck, wav, wlen = make_case_checkpoint(name)
     gold = dict(np.load(os.path.join(ROOT, "tests", "golden", name + ".npz")))
     return ck, wav, wlen, gold
+
+
+def golden_trace(gold):
+    """Per-utterance joint log-probs of the REFERENCE's RNN-T greedy decode, in decode order."""
+    out, o = [], 0
+    for c in gold["trace_counts"].tolist():
+        out.append(torch.from_numpy(gold["trace"][o:o + c]))
+        o += c
+    return out
 
 
 def oracle_features(ck, wav, wlen):

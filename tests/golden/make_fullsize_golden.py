@@ -1,0 +1,118 @@
+"""Full-size (16-layer) golden vectors for BASELINE.json configs 2-4 -- runs ONLY in the build container.
+
+The reference's own ConformerEncoder / CTCHead / RNNTHead / greedy decoders (through oracle/ref_shim.py) on
+the FIRST FOUR utterances of the batches bench.py times:
+  fullsize_v2_ctc       config 2: v2_ctc seed 0, synth_audio(32, 20 s, seed 1000)[:4]
+  fullsize_v2_rnnt      config 3: v2_rnnt seed 0, same audio, blank-dominant head
+  fullsize_v3_e2e_rnnt  config 4: v3_e2e_rnnt seed 0 (V = 1025), the 4 longest of the 1024-utterance set's
+                        first batch, blank-dominant head
+The RNN-T blank bias is searched so that (a) the decode is blank-dominant (0.1-0.6 symbols per frame, the regime
+of reference gigaam/decoding.py:162-205 on trained models) and (b) the oracle's top-1/top-2 margin exceeds 2e-3
+on every joint step of these utterances; the chosen value goes to fullsize_meta.json, which bench.py reads so the
+timed run and the parity check use the SAME head.
+
+    python tests/golden/make_fullsize_golden.py
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+from gigaam_amd import synth, workloads  # noqa: E402
+from oracle import gigaam_oracle as O  # noqa: E402
+from oracle.ref_shim import import_reference  # noqa: E402
+from make_golden import kw, strip  # noqa: E402
+
+N_UTT = 4
+BIASES = [16.0, 15.0, 17.0, 14.0, 18.0, 13.0, 19.0, 12.0, 20.0, 11.0]
+
+
+def audio_for(name):
+    if name == "fullsize_v3_e2e_rnnt":
+        wav, wlen = workloads.config4_batches(n_utts=1024, batch=32, only_batches=[0])[0][:2]
+        return wav[:N_UTT].contiguous(), wlen[:N_UTT].contiguous()
+    wav, wlen = workloads.config2_batch(32, 20.0, rank=0)
+    return wav[:N_UTT].contiguous(), wlen[:N_UTT].contiguous()
+
+
+def main():
+    torch.set_num_threads(os.cpu_count())
+    ref = import_reference()
+    meta_path = os.path.join(HERE, "fullsize_meta.json")
+    meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
+    for name, model in [("fullsize_v2_ctc", "v2_ctc"), ("fullsize_v2_rnnt", "v2_rnnt"), ("fullsize_v3_e2e_rnnt", "v3_e2e_rnnt")]:
+        wav, wlen = audio_for(name)
+        ck = synth.make_checkpoint(model, seed=0)
+        cfg, sd = ck["cfg"], ck["state_dict"]
+        with torch.no_grad():
+            feat, flen = O.log_mel(wav, wlen, cfg["preprocessor"], sd["preprocessor.featurizer.0.spectrogram.window"],
+                                   sd["preprocessor.featurizer.0.mel_scale.fb"])
+            enc = ref.encoder.ConformerEncoder(**kw(cfg["encoder"])).eval()
+            enc.load_state_dict(strip(sd, "encoder."))
+            y_ref, l_ref = enc(feat, flen)
+            y_or, l_or = O.encoder_forward(sd, cfg["encoder"], feat, flen)
+            valid = (torch.arange(y_ref.shape[2])[None, :] < l_ref[:, None])[:, None, :]
+            d_enc = float(((y_ref - y_or) * valid).abs().max())
+            assert l_ref.tolist() == l_or.tolist() and d_enc < 5e-5, d_enc
+            out = dict(enc_len=l_ref.numpy(), enc_probe=y_ref[:, ::16, ::5].numpy(), wav_len=wlen.numpy())
+            st = dict(model=model, n_utts=N_UTT, enc_absdiff_oracle_vs_ref=d_enc, frames=l_ref.tolist())
+            if model.endswith("ctc"):
+                head = ref.decoder.CTCHead(**kw(cfg["head"])).eval()
+                head.load_state_dict(strip(sd, "head."))
+                dec = ref.decoding.CTCGreedyDecoding(cfg["decoding"]["vocabulary"])
+                r = dec.decode(head, y_ref, l_ref)
+                lp = head(y_ref)
+                top2 = lp.topk(2, dim=-1).values
+                st["min_margin"] = float((top2[..., 0] - top2[..., 1])[valid[:, 0, :]].min())
+                o = O.ctc_greedy(O.ctc_log_probs(sd, y_ref), l_ref)
+            else:
+                v = cfg["head"]["decoder"]["num_classes"]
+                ms = cfg["decoding"]["max_symbols_per_step"]
+                default_bias = float(sd["head.joint.joint_net.1.bias"][v - 1])
+                base = default_bias - (5.3 + 0.35 * np.log(v))
+                chosen = None
+                for bb in BIASES:
+                    sd["head.joint.joint_net.1.bias"][v - 1] = base + bb
+                    trace = []
+                    o = O.rnnt_greedy(sd, y_ref, l_ref, ms, trace=trace)
+                    marg = min(float(t[2].topk(2).values[0] - t[2].topk(2).values[1]) for t in trace)
+                    spf = sum(len(a) for a, _ in o) / int(l_ref.sum())
+                    print(name, "bias", bb, "sym/frame %.3f" % spf, "min margin %.2e" % marg, flush=True)
+                    if 0.1 <= spf <= 0.6 and marg > 2e-3 and min(len(a) for a, _ in o) > 3:
+                        chosen = bb
+                        break
+                assert chosen is not None, name
+                ck2 = synth.make_checkpoint(model, seed=0, rnnt_blank_bias=chosen)
+                assert torch.equal(ck2["state_dict"]["head.joint.joint_net.1.bias"], sd["head.joint.joint_net.1.bias"])
+                head = ref.decoder.RNNTHead(cfg["head"]["decoder"], cfg["head"]["joint"]).eval()
+                head.load_state_dict(strip(sd, "head."))
+                dec = ref.decoding.RNNTGreedyDecoding(cfg["decoding"]["vocabulary"], max_symbols_per_step=ms)
+                r = dec.decode(head, y_ref, l_ref)
+                st.update(blank_bias=chosen, min_margin=marg, symbols_per_frame=round(spf, 3), joint_steps=len(trace))
+                # top-4 log-probs of every joint step, per utterance in order (the full [steps, V] dump is too big to commit)
+                tv = torch.stack([t[2].topk(4).values for t in trace])
+                ti = torch.stack([t[2].topk(4).indices for t in trace])
+                out.update(trace_top_vals=tv.numpy(), trace_top_idx=ti.numpy().astype(np.int32),
+                           trace_counts=np.asarray([sum(1 for t in trace if t[0] == i) for i in range(N_UTT)], np.int32))
+            ids_flat, frames_flat, counts = [], [], []
+            for (_t, ids, fr), (oi, of) in zip(r, o):
+                assert ids == oi and fr == of, name
+                ids_flat += ids
+                frames_flat += fr
+                counts.append(len(ids))
+            out.update(ids=np.asarray(ids_flat, np.int32), frames=np.asarray(frames_flat, np.int32), counts=np.asarray(counts, np.int32))
+            st["counts"] = counts
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        meta[name] = st
+        print(name, json.dumps(st), flush=True)
+    json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -22,19 +22,10 @@ from gigaam_amd import synth  # noqa: E402
 from oracle import gigaam_oracle as O  # noqa: E402
 from oracle.ref_shim import import_reference  # noqa: E402
 
-# name -> (model, ckpt seed, n_layers, audio: (batch, seconds, seed, lengths))
-CASES = {
-    "v2_ctc_l2": ("v2_ctc", 1, 2, (3, 4.0, 11, [64000, 50000, 33333])),
-    "v2_ctc_l2_b1": ("v2_ctc", 1, 2, (1, 2.5, 12, None)),
-    "v2_rnnt_l2": ("v2_rnnt", 1, 2, (3, 4.0, 13, [64000, 41234, 57000])),
-    "v3_ctc_l2": ("v3_ctc", 1, 2, (3, 4.0, 14, [64000, 50000, 33333])),
-    "v3_e2e_rnnt_l2": ("v3_e2e_rnnt", 1, 2, (2, 3.0, 15, [48000, 30011])),
-    "v1_ctc_l2": ("v1_ctc", 1, 2, (3, 3.0, 16, [48000, 40000, 20000])),
-    "v2_ctc_l2_short": ("v2_ctc", 1, 2, (2, 0.3125, 17, [5000, 3200])),  # reference tests/test_batching.py:125-140
-    "v3_e2e_ctc_l2": ("v3_e2e_ctc", 1, 2, (2, 3.0, 19, [48000, 35000])),
-    "v1_rnnt_l2": ("v1_rnnt", 1, 2, (2, 2.5, 20, [40000, 26000])),
-    "emo_l2": ("emo", 1, 2, (2, 3.0, 18, [48000, 36000])),
-}
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from cases import CASES, EMO_CASE, RNNT_MIN_MARGIN, make_case_checkpoint  # noqa: E402
+
+ALL_CASES = dict(CASES, emo_l2=EMO_CASE)
 
 
 def strip(sd, prefix):
@@ -46,10 +37,9 @@ def kw(d):
 
 
 def run_case(ref, case):
-    model, seed, nl, (b, secs, aseed, lens) = CASES[case]
-    ck = synth.make_checkpoint(model, seed=seed, n_layers=nl)
+    ck, wav, wlen = make_case_checkpoint(ALL_CASES[case])
     cfg, sd = ck["cfg"], ck["state_dict"]
-    wav, wlen = synth.synth_audio(b, secs, seed=aseed, lengths=lens)
+    b = wav.shape[0]
     out = {}
     with torch.no_grad():
         feat, flen = O.log_mel(wav, wlen, cfg["preprocessor"],
@@ -125,6 +115,33 @@ def run_case(ref, case):
             stats["joint_steps"] = len(trace)
             marg = [float(t[2].topk(2).values[0] - t[2].topk(2).values[1]) for t in trace]
             stats["min_margin"] = min(marg)
+            assert min(marg) > RNNT_MIN_MARGIN, (case, min(marg))
+            # The REFERENCE's joint log-probs of every step, per sample in decode order: the reference's own
+            # RNNTGreedyDecoding.decode run one sample at a time with RNNTJoint.joint wrapped by a recorder
+            # (decoder.py:41-47 untouched).  This is what the HIP kernel's logits dump is compared with.
+            ref_trace, ref_counts = [], []
+            orig_joint = head.joint.joint
+            for i in range(b):
+                rec = []
+                head.joint.joint = lambda f, g, rec=rec: (rec.append(orig_joint(f, g)), rec[-1])[1]
+                r1 = dec.decode(head, y_ref[i:i + 1, :, : int(l_ref[i])].contiguous(), l_ref[i:i + 1])
+                assert r1[0][1] == r[i][1] and r1[0][2] == r[i][2], (case, i)
+                steps = torch.cat([x.reshape(-1, x.shape[-1]) for x in rec])
+                per = torch.stack([t[2] for t in trace if t[0] == i])
+                assert steps.shape == per.shape, (steps.shape, per.shape)
+                assert float((steps - per).abs().max()) < 2e-5, (case, i, float((steps - per).abs().max()))
+                ref_trace.append(steps)
+                ref_counts.append(steps.shape[0])
+            head.joint.joint = orig_joint
+            out["trace"] = torch.cat(ref_trace).numpy()
+            out["trace_counts"] = np.asarray(ref_counts, np.int32)
+            n_frames = int(l_ref.sum())
+            n_tok = sum(len(x[1]) for x in r)
+            stats["symbols_per_frame"] = round(n_tok / n_frames, 3)
+            from collections import Counter
+            stats["max_symbols_on_a_frame"] = max(max(Counter(x[2]).values()) if x[2] else 0 for x in r)
+            stats["max_symbols_per_step"] = ms
+            stats["blank_step_frac"] = round(1.0 - n_tok / len(trace), 3)
             # pin predict/joint against the reference modules on the first steps
             g_ref, (h_ref, c_ref) = head.decoder.predict(None, None, batch_size=1)
             g_or, (h_or, c_or) = O.rnnt_predict(sd, None, None)
@@ -138,7 +155,6 @@ def run_case(ref, case):
             j_or = O.rnnt_joint(sd, f[0, 0], g2_or)
             assert float((j_ref - j_or).abs().max()) < 2e-5
             out["joint_probe"] = j_ref.numpy()
-            out["trace_first"] = torch.stack([t[2] for t in trace[:64]]).numpy()
         ids_flat, frames_flat, counts = [], [], []
         for (txt, ids, fr), (oi, of) in zip(r, o):
             assert ids == oi and fr == of, (case, ids[:10], oi[:10])
@@ -159,7 +175,7 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     all_stats = {}
     only = [a for a in sys.argv[1:] if not a.startswith("-")]
-    for case in CASES:
+    for case in ALL_CASES:
         if only and case not in only:
             continue
         out, stats = run_case(ref, case)

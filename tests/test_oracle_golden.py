@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from common import CASES, load_case, oracle_features, split_ragged, valid_mask
+from common import CASES, RNNT_MIN_MARGIN, golden_trace, load_case, oracle_features, split_ragged, valid_mask
 from oracle import gigaam_oracle as O
 
 
@@ -33,9 +33,29 @@ def test_oracle_matches_reference_golden(case):
         else:
             trace = []
             got = O.rnnt_greedy(sd, enc_ref, elen, cfg["decoding"]["max_symbols_per_step"], trace=trace)
-            first = torch.stack([t[2] for t in trace[:64]])
-            assert float((first - torch.from_numpy(gold["trace_first"])).abs().max()) < 2e-5
+            # every joint evaluation against the reference's own (RNNTJoint.joint recorded during its decode)
+            for i, want in enumerate(golden_trace(gold)):
+                mine = torch.stack([t[2] for t in trace if t[0] == i])
+                assert mine.shape == want.shape and float((mine - want).abs().max()) < 2e-5
+                top2 = want.topk(2, dim=-1).values
+                assert float((top2[:, 0] - top2[:, 1]).min()) > RNNT_MIN_MARGIN   # no near-tie anywhere in the fixture
     assert got == ref
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_frontend_against_torchaudio_fixture(case):
+    """Row a1 against torchaudio's own MelSpectrogram + the reference's SpecScaler, when the fixture exists."""
+    from common import frontend_fixture
+    fx = frontend_fixture(case)
+    if fx is None:
+        pytest.skip("a1 parity unpinned: no torchaudio here; run tests/golden/make_frontend_golden.py where it is installed")
+    ck, wav, wlen, _ = load_case(case)
+    feat, flen = oracle_features(ck, wav, wlen)
+    assert flen.tolist() == fx["feat_len"].tolist() and tuple(feat.shape) == fx["feat"].shape
+    from common import TOL_FEAT, TOL_FEAT_WEAK, logmel_err
+    fm = valid_mask(feat.shape[2], flen)
+    e_strong, e_weak = logmel_err(feat, torch.from_numpy(fx["feat"]), fm)
+    assert e_strong < TOL_FEAT and e_weak < TOL_FEAT_WEAK, (e_strong, e_weak)
 
 
 def test_emotion_head_oracle_matches_reference_golden():
@@ -44,9 +64,9 @@ def test_emotion_head_oracle_matches_reference_golden():
     import os
     from common import EMO_CASE, ROOT
     from gigaam_amd import synth
-    model, seed, nl, (b, secs, aseed, lens) = EMO_CASE
-    ck = synth.make_checkpoint(model, seed=seed, n_layers=nl)
-    wav, wlen = synth.synth_audio(b, secs, seed=aseed, lengths=lens)
+    from common import make_case_checkpoint
+    ck, wav, wlen = make_case_checkpoint(EMO_CASE)
+    b = wav.shape[0]
     gold = dict(np.load(os.path.join(ROOT, "tests", "golden", "emo_l2.npz")))
     sd, cfg = ck["state_dict"], ck["cfg"]
     torch.set_num_threads(8)
