@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
 """Throughput bench of the MI355X hot path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W                      # the driver's command: config 2, weak scaling
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+    python bench.py --config {1,2,3,4,5} [--scaling weak|strong] [--gather rccl|torch] [--gemm f16x3|f32]
 
-One step = one pass of the whole hot path over one batch of synthetic audio that is
-already resident in HBM:  log-mel frontend -> 16-layer Conformer encoder -> CTC head +
-greedy collapse  (BASELINE.json configs[1]: v2_ctc, batch 32 x 20 s per GPU), followed
-by the only exchange the path has: an all-gather of the decoded (counts, ids, frames)
-over RCCL.  Utterances are independent, so ranks shard the batch and scaling is weak
-(32 utterances per GPU).  Weights are random-init tensors of the exact v2_ctc
-architecture (gigaam_amd/synth.py; no checkpoints offline), arithmetic is fp32.
+One step = one pass of the whole hot path over one batch (config 4/5: one pass over the rank's share of the
+set) of synthetic audio: log-mel frontend -> 16-layer Conformer encoder -> greedy decode -> decoded ids on the
+HOST (the D2H copy the product's transcribe path always pays), followed by the only exchange the path has: a
+gather of the decoded (index, counts, ids, frames) over RCCL (gam_gather_ids, include/gigaam_hip.h).
+
+  config 2 (default, the headline; BASELINE.json configs[1])  v2_ctc, 32 x 20 s
+  config 3  v2_rnnt, same audio, blank-dominant synthetic head (tests/golden/fullsize_meta.json)
+  config 1  v2_ctc, one 5 s clip
+  config 4  v3_e2e_rnnt (V = 1025), 128 utterances per GPU (weak; 1024 at 8 GPUs) or 1024 in total (strong),
+            durations U(5 s, 20 s), sorted into 32-utterance batches dealt to the ranks
+  config 5  v2_ctc longform: 1 h of audio, the reference's chunk packer, batches of 16 dealt round-robin to
+            the ranks and streamed through the pinned double-buffered feeder (always strong scaling)
+--scaling weak: per-GPU work fixed (32 utterances per GPU); strong: the global batch of 32 split over the ranks.
+
+Utterances are independent, so ranks own disjoint utterances with replicated weights.  Weights are random-init
+tensors of the exact architecture (gigaam_amd/synth.py; no checkpoints offline), arithmetic is fp32.
 
 Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
-  roofline     -- the dominant kernel (the fp32 MFMA GEMM family, incl. the implicit-GEMM
-                  stem conv), timed with HIP events on the launch stream inside the
-                  timed region; achieved = algorithmic FLOP / event time.
-  cpu_baseline -- the CPU oracle (a port of the reference's fp32 CPU path) timed on this
-                  box's host cores on a bounded sample of the same workload (N=1 only).
+  roofline            the dominant kernel family (the GEMMs, incl. the implicit-GEMM stem conv), timed with HIP
+                      events on the launch stream inside the timed region; achieved = algorithmic FLOP / event time
+  roofline_f32_exact  the same steps re-timed with the dense contractions on exact-fp32 MFMA (the reference's own
+                      arithmetic), so that figure is on the driver's clock too
+  cpu_baseline        the CPU oracle (a port of the reference's fp32 CPU path) on this box's host cores (N=1 only)
 """
 from __future__ import annotations
 
@@ -34,6 +44,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+from gigaam_amd import shard  # noqa: E402
+from gigaam_amd.shard import shard_range  # noqa: E402,F401  (re-exported: tests/test_distributed_gloo.py)
+
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 F16_MFMA_PEAK_TFLOPS = 2500.0   # same guide: dense fp16/bf16 MFMA (32x32x16)
 FLOP_PER_UTT_20S_V2 = 325.9e9   # SURVEY.md §8d / BASELINE.md §3
@@ -44,24 +57,10 @@ def world() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-def shard_range(n_items: int, rank: int, n_ranks: int):
-    """Contiguous block of ceil(n/ranks) items per rank."""
-    per = (n_items + n_ranks - 1) // n_ranks
-    return min(n_items, rank * per), min(n_items, (rank + 1) * per)
-
-
 def gather_decoded(counts: torch.Tensor, ids: torch.Tensor, frames: torch.Tensor):
-    """The path's one exchange step: all-gather of the fixed-size padded decode buffers
-    (<= 4 KB per utterance, latency-bound).  Rank-major order."""
-    if world() == 1:
-        return counts, ids, frames
-    n = world()
-    outs = []
-    for t in (counts, ids, frames):
-        buf = [torch.empty_like(t) for _ in range(n)]
-        dist.all_gather(buf, t.contiguous())
-        outs.append(torch.cat(buf, dim=0))
-    return tuple(outs)
+    """torch.distributed form of the path's one exchange (rank-major); see shard.torch_gather."""
+    _, c, i, f = shard.torch_gather(None, counts, ids, frames)
+    return c, i, f
 
 
 def max_over_ranks(seconds: float) -> float:
@@ -82,45 +81,107 @@ def barrier_sync():
         dist.barrier()
 
 
+def make_gather(kind: str, rank: int, n_ranks: int, dev: torch.device):
+    """The exchange callable (index, counts, ids, frames) -> the same, rank-major.  "rccl": gam_gather_ids behind
+    the C ABI (the RCCL id travels over torch.distributed's store); "torch": dist.all_gather (cross-check)."""
+    if kind == "rccl":
+        def exchange(uid):
+            if n_ranks == 1:
+                return uid
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        comm = shard.HipComm(rank, n_ranks, dev, exchange)
+        return comm.gather, "gam_gather_ids (RCCL ncclAllGather behind the C ABI)"
+
+    def tg(index, counts, ids, frames):
+        mv = lambda t: None if t is None else t.to(dev)  # noqa: E731
+        return shard.torch_gather(mv(index), mv(counts), mv(ids), mv(frames))
+    return tg, "torch.distributed all_gather (RCCL)"
+
+
 # ----------------------------------------------------------------------------- cpu baseline
-def cpu_baseline(ckpt, wav, wlen, n_utts: int, gpu_decoded):
-    """CPU oracle (fp32, all host cores) on the first n_utts utterances; also reports
-    whether the GPU ids/frames of those utterances are identical."""
+def cpu_baseline(ckpt, wav, wlen, n_utts: int, gpu_decoded, sweep: bool):
+    """The CPU oracle (fp32 port of the reference's CPU path) on this box's host cores.  With ``sweep`` the thread
+    count is chosen by timing a small sample at 8 / 32 / 64 / all cores (many small fp32 ops: beyond a few dozen
+    threads the oracle gets slower on a many-core host), then all ``n_utts`` utterances run at the best setting.
+    Also reports how many of those utterances decode to exactly the GPU's ids/frames."""
     from oracle import gigaam_oracle as O
-    # many small fp32 ops: beyond ~32 threads the oracle gets SLOWER on a many-core host
-    # (256 threads measured 1.2x real time vs 8 threads ~24x), so cap and report the count
-    threads = min(32, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
+    ncpu = os.cpu_count() or 1
     w, l = wav[:n_utts].cpu(), wlen[:n_utts].cpu()
+    sweep_out = {}
+    best = min(32, ncpu)
     with torch.no_grad():
+        torch.set_num_threads(best)
         O.transcribe_ids(ckpt, w[:1, :16000].contiguous(), torch.tensor([16000]))  # warm-up
+        if sweep:
+            for th in sorted({min(8, ncpu), min(32, ncpu), min(64, ncpu), ncpu}):
+                torch.set_num_threads(th)
+                k = 1 if th > 64 else min(2, n_utts)     # the all-cores point runs ~1x real time: one utterance only
+                t0 = time.perf_counter()
+                O.transcribe_ids(ckpt, w[:k], l[:k])
+                sweep_out[th] = round(float(l[:k].sum()) / 16000.0 / (time.perf_counter() - t0), 2)
+            best = max(sweep_out, key=sweep_out.get)
+        torch.set_num_threads(best)
         t0 = time.perf_counter()
         dec, _, _ = O.transcribe_ids(ckpt, w, l)
         dt = time.perf_counter() - t0
     audio_s = float(l.sum()) / 16000.0
     same = [list(a) == list(b) and list(c) == list(d) for (a, c), (b, d) in zip(dec, gpu_decoded[:n_utts])]
-    return {
-        "value": round(audio_s / dt, 3), "unit": "audio-sec/wall-sec", "cores": threads,
-        "host_cpus": os.cpu_count(), "kind": "port",
-        "sample": f"{n_utts} of the batch's utterances ({audio_s:.0f} s audio), oracle/gigaam_oracle.py fp32, {dt:.1f} s wall",
+    out = {
+        "value": round(audio_s / dt, 3), "unit": "audio-sec/wall-sec", "cores": best, "host_cpus": ncpu, "kind": "port",
+        "sample": f"{n_utts} utterances of the timed batch ({audio_s:.0f} s audio), oracle/gigaam_oracle.py fp32, {dt:.1f} s wall",
         "gpu_ids_identical": f"{sum(same)}/{len(same)}",
+        "reference_cpu": "unavailable on the GPU box (/root/reference is not shipped); the oracle is pinned to the reference's "
+                         "own modules by tests/golden/*.npz",
     }
+    if sweep_out:
+        out["thread_sweep_rtfx"] = {str(k): v for k, v in sweep_out.items()}
+    if sum(same) != len(same):
+        out["mismatching_utterances"] = [i for i, s in enumerate(same) if not s]
+    return out
 
 
-# ----------------------------------------------------------------------------- main
+# ----------------------------------------------------------------------------- workloads
+def rnnt_bias_for(model_name: str, override):
+    """Blank bias of the synthetic RNN-T head: the blank-dominant value the full-size goldens were made with."""
+    if override is not None:
+        return override
+    meta = os.path.join(ROOT, "tests", "golden", "fullsize_meta.json")
+    if os.path.exists(meta):
+        m = json.load(open(meta)).get(f"fullsize_{model_name}")
+        if m:
+            return m.get("blank_bias")
+    return None
+
+
+def ragged_host(ids, frames, counts):
+    """Decoded buffers -> host lists: the blocking D2H + slicing of gigaam_amd.decoding._ragged."""
+    n = counts.cpu().tolist()
+    width = max(n) if n else 0
+    ih, fh = ids[:, :width].cpu(), frames[:, :width].cpu()
+    return [(ih[i, :c].tolist(), fh[i, :c].tolist()) for i, c in enumerate(n)]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--model", default="v2_ctc")
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4, 5], help="BASELINE.json configuration (default 2: the headline)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--gather", default="rccl", choices=["rccl", "torch"], help="the final exchange: gam_gather_ids (C ABI) or torch.distributed")
+    ap.add_argument("--model", default=None, help="override the configuration's model")
+    ap.add_argument("--batch", type=int, default=32, help="configs 2/3: utterances per GPU (weak) or in total (strong)")
     ap.add_argument("--seconds", type=float, default=20.0)
+    ap.add_argument("--utts-per-gpu", type=int, default=128, help="config 4, weak scaling")
+    ap.add_argument("--longform-seconds", type=int, default=3600, help="config 5")
     ap.add_argument("--layers", type=int, default=-1, help="debug only: fewer layers INVALIDATES the number")
-    ap.add_argument("--cpu-utts", type=int, default=8, help="utterances in the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-utts", type=int, default=-1, help="utterances in the CPU-oracle leg (0 = skip; default: 32 for config 2, 4 otherwise)")
     ap.add_argument("--rnnt-blank-bias", type=float, default=None,
-                    help="RNN-T models: blank bias of the synthetic joint (default: emission-heavy synthetic head)")
+                    help="RNN-T models: blank bias of the synthetic joint (default: the blank-dominant value of tests/golden/fullsize_meta.json)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
+    ap.add_argument("--no-f32-leg", action="store_true", help="skip the exact-fp32 re-timing (roofline_f32_exact)")
     ap.add_argument("--gemm", default="f16x3", choices=["f16x3", "f32"],
                     help="dense-contraction arithmetic: split-fp16 MFMA (fp32-equivalent, default) or exact fp32 MFMA")
     args = ap.parse_args()
@@ -138,42 +199,127 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import gigaam_amd
-    from gigaam_amd import synth
+    from gigaam_amd import synth, workloads
 
+    cfgno = args.config
+    model_name = args.model or {1: "v2_ctc", 2: "v2_ctc", 3: "v2_rnnt", 4: "v3_e2e_rnnt", 5: "v2_ctc"}[cfgno]
     over = {} if args.layers < 0 else {"n_layers": args.layers}
-    ckpt = synth.make_checkpoint(args.model, seed=0, rnnt_blank_bias=args.rnnt_blank_bias, **over)
+    is_rnnt = model_name.endswith("rnnt")
+    bias = rnnt_bias_for(model_name, args.rnnt_blank_bias) if is_rnnt else None
+    ckpt = synth.make_checkpoint(model_name, seed=0, rnnt_blank_bias=bias, **over)
     model = gigaam_amd.model_from_checkpoint(ckpt, dev)
     eng = model.encoder.engine
     eng.set_gemm_mode(args.gemm)
-    is_ctc = ckpt["cfg"]["head"]["_target_"].endswith("CTCHead")
     max_sym = ckpt["cfg"]["decoding"].get("max_symbols_per_step", 10)
+    gather, gather_name = make_gather(args.gather, rank, n_ranks, dev)
+    scaling = "strong" if cfgno == 5 else args.scaling
 
-    # this rank's shard of the global batch: `batch` utterances, seeded by global index
-    g0, g1 = shard_range(args.batch * n_ranks, rank, n_ranks)
-    wav_h, wlen_h = synth.synth_audio(g1 - g0, args.seconds, seed=1000 + rank)
-    wav, wlen = wav_h.to(dev), wlen_h.to(dev)          # resident in HBM before the timed region
-
-    def step():
+    def decode_dev(wav, wlen):
         feat, flen = eng.frontend(wav, wlen)
         enc, elen = eng.encode(feat, flen)
-        if is_ctc:
-            ids, frames, counts = eng.ctc_greedy(enc, elen)
+        return eng.rnnt_greedy(enc, elen, max_sym) if is_rnnt else eng.ctc_greedy(enc, elen)
+
+    def decode_batch(wav, wlen):
+        return ragged_host(*decode_dev(wav, wlen))
+
+    # ---- the step of each configuration; `audio_s` = audio seconds ALL ranks process per step
+    cpu_sample = None       # (wav, wlen) on the host + global indices, for the CPU-oracle leg
+    if cfgno in (1, 2, 3):
+        if cfgno == 1:
+            n_global, seconds = 1, 5.0
+            g0, g1 = (0, 1) if rank == 0 else (0, 0)
         else:
-            ids, frames, counts = eng.rnnt_greedy(enc, elen, max_sym)
-        return gather_decoded(counts, ids, frames)
+            n_global = args.batch * (n_ranks if scaling == "weak" else 1)
+            seconds = args.seconds
+            g0, g1 = shard_range(n_global, rank, n_ranks)
+        wav_h, wlen_h = workloads.config2_batch(max(1, g1 - g0), seconds, first=g0) if cfgno != 1 else workloads.config1_clip()
+        wav, wlen = wav_h.to(dev), wlen_h.to(dev)          # resident in HBM before the timed region
+        rows = max(shard_range(n_global, r, n_ranks)[1] - shard_range(n_global, r, n_ranks)[0] for r in range(n_ranks))
+        audio_s = seconds * n_global
+        idx_dev = torch.full((rows,), -1, dtype=torch.int32, device=dev)
+        idx_dev[: g1 - g0] = torch.arange(g0, g1, dtype=torch.int32, device=dev)
+        cpu_sample = (wav_h, wlen_h, list(range(g0, g1)))
+
+        def step():
+            if g1 > g0:
+                ids, frames, counts = decode_dev(wav, wlen)
+            else:   # strong scaling with more ranks than utterances: this rank only takes part in the exchange
+                cap0 = eng.enc_frames(eng.feat_frames(int(seconds * 16000))) * (max_sym if is_rnnt else 1)
+                ids = frames = torch.zeros((0, cap0), dtype=torch.int32, device=dev)
+                counts = torch.zeros((0,), dtype=torch.int32, device=dev)
+            if n_ranks > 1:
+                pad = rows - ids.shape[0]
+                if pad:
+                    ids = torch.cat([ids, ids.new_zeros((pad, ids.shape[1]))])
+                    frames = torch.cat([frames, frames.new_zeros((pad, frames.shape[1]))])
+                    counts = torch.cat([counts, counts.new_zeros((pad,))])
+                gi, gc, gids, gfr = gather(idx_dev, counts, ids, frames)
+                keep = gi >= 0
+                ids, frames, counts = gids[keep], gfr[keep], gc[keep]
+            return ragged_host(ids, frames, counts)        # the decoded ids end every step on the host
+        workload = (f"{model_name} (16-layer Conformer, random-init weights), {n_global} x {seconds:g} s 16 kHz utterances "
+                    f"({'%d per GPU' % args.batch if scaling == 'weak' else 'global batch split over the ranks'}), frontend + encoder + "
+                    f"{'RNN-T' if is_rnnt else 'CTC'} greedy + ids to host, final gather of ids")
+    elif cfgno == 4:
+        n_utts = args.utts_per_gpu * n_ranks if scaling == "weak" else 1024
+        mine = shard.deal((n_utts + 31) // 32, rank, n_ranks)
+        host_batches = workloads.config4_batches(n_utts, 32, only_batches=set(range((n_utts + 31) // 32)) if n_ranks == 1 else None)
+        batches = [(w.to(dev) if j in mine else w, l.to(dev) if j in mine else l, g) for j, (w, l, g) in enumerate(host_batches)]
+        audio_s = float(sum(int(l.sum()) for _, l, _ in host_batches)) / 16000.0
+        cap = eng.enc_frames(eng.feat_frames(20 * 16000)) * max_sym
+        tok = model.decoding.tokenizer
+        if rank == 0 and host_batches:
+            cpu_sample = (host_batches[mine[0]][0], host_batches[mine[0]][1], host_batches[mine[0]][2])
+
+        def step():
+            res = shard.run_sharded(batches, decode_batch, rank, n_ranks, gather, cap, my_batches=mine)
+            return res if rank != 0 else [(i, f, tok.decode(i)) for i, f in res]     # detokenised like the package API
+        workload = (f"{model_name} (V = 1025), {n_utts} utterances with durations U(5 s, 20 s) sorted into 32-utterance batches "
+                    f"dealt to {n_ranks} rank(s) ({len(mine)} batches on rank 0), frontend + encoder + RNN-T greedy + ids to host + "
+                    "gather + detokenise")
+    else:
+        from gigaam_amd.feeder import BatchFeeder
+        segs, bounds = workloads.config5_segments(args.longform_seconds)
+        fr_bs = 16
+        n_b = (len(segs) + fr_bs - 1) // fr_bs
+        mine = shard.deal(n_b, rank, n_ranks, snake=False)      # round-robin, in file order
+        my_segs = [s for j in mine for s in segs[j * fr_bs:(j + 1) * fr_bs]]
+        my_idx = [i for j in mine for i in range(j * fr_bs, min(len(segs), (j + 1) * fr_bs))]
+        per_rank = max(sum(min(len(segs), (j + 1) * fr_bs) - j * fr_bs for j in shard.deal(n_b, r, n_ranks, snake=False)) for r in range(n_ranks))
+        cap = eng.enc_frames(eng.feat_frames(30 * 16000 + 160))
+        audio_s = float(args.longform_seconds)
+        tok = model.decoding.tokenizer
+
+        def step():
+            rows, o = [], 0
+            for wav_b, len_b in BatchFeeder(my_segs, fr_bs, dev):            # pinned, double-buffered H2D
+                for i, f in decode_batch(wav_b, len_b):
+                    rows.append((my_idx[o], i, f))
+                    o += 1
+            res = shard.unpack_results(*gather(*shard.pack_results(rows, per_rank, cap)), len(segs))
+            return res if rank != 0 else [(tok.decode(i), bounds[k]) for k, (i, f) in enumerate(res)]
+        workload = (f"{model_name} longform: {args.longform_seconds} s of audio -> {len(segs)} chunks (reference packer 22/15/30/0.2 s) -> "
+                    f"batches of 16 dealt round-robin to {n_ranks} rank(s), streamed from host memory through the pinned "
+                    "double-buffered feeder, CTC greedy, gather, detokenise")
+
+    # ---- timing: W warm-up steps, then EXACTLY K steps between barrier + synchronize pairs; max over ranks
+    def timed(k_steps, profile):
+        barrier_sync()
+        if profile:
+            eng.profile_enable(2)      # inside the timed region: events around the GEMM family only
+        t0 = time.perf_counter()
+        out_ = None
+        for _ in range(k_steps):
+            out_ = step()
+        barrier_sync()
+        return max_over_ranks(time.perf_counter() - t0), out_
 
     for _ in range(args.warmup):
         step()
-    barrier_sync()
-    if not args.no_profile:
-        eng.profile_enable(2)      # inside the timed region: events around the GEMM family only
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier_sync()
-    dt = max_over_ranks(time.perf_counter() - t0)
+    do_prof = not args.no_profile
+    dt, out = timed(args.steps, do_prof)
     prof = prof_all = None
-    if not args.no_profile:
+    if do_prof:
         prof = eng.profile_read()
         eng.profile_enable(1)      # one extra, untimed step for the per-class breakdown
         step()
@@ -181,38 +327,59 @@ def main():
         prof_all = eng.profile_read()
         eng.profile_enable(0)
 
+    # exact-fp32 leg: the same steps with the dense contractions on v_mfma_f32_32x32x2_f32 (the reference's arithmetic)
+    f32_leg = None
+    if args.gemm == "f16x3" and not args.no_f32_leg and cfgno in (2, 3):
+        eng.set_gemm_mode("f32")
+        for _ in range(2):
+            step()
+        dt32, out32 = timed(args.steps, do_prof)
+        p32 = eng.profile_read() if do_prof else None
+        eng.profile_enable(0)
+        eng.set_gemm_mode("f16x3")
+        f32_leg = (dt32, out32, p32)
+
     if rank != 0:
         if n_ranks > 1:
             dist.destroy_process_group()
         return
 
-    audio_s = args.seconds * args.batch * n_ranks * args.steps
     ms_step = dt / args.steps * 1e3
-    counts, ids, frames = out
-    n_c = counts.cpu().tolist()
-    decoded = [(ids[i, :c].cpu().tolist(), frames[i, :c].cpu().tolist()) for i, c in enumerate(n_c[: g1 - g0])]
+    fam = ("gemm", "conv2")   # one kernel family: the GEMMs incl. the implicit-GEMM stem conv
+
+    def family(p, peak):
+        flop = sum(p[k]["work"] for k in fam)
+        ms = sum(p[k]["ms"] for k in fam)
+        n = sum(p[k]["launches"] for k in fam)
+        ach = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return flop, ms, n, ach, ach / peak
+
+    metric = {1: "RTFx v2_ctc single 5 s clip", 2: f"RTFx {model_name} batch{args.batch}x{args.seconds:g}s (log-mel + encoder + greedy decode)",
+              3: f"RTFx {model_name} batch{args.batch}x{args.seconds:g}s (log-mel + encoder + RNN-T greedy decode)",
+              4: "RTFx v3_e2e_rnnt utterance set sharded over the ranks", 5: "RTFx v2_ctc longform streamed over the ranks"}[cfgno]
+    n_units = {1: 1, 2: args.batch, 3: args.batch}.get(cfgno)
     line = {
-        "metric": f"RTFx {args.model} batch{args.batch}x{args.seconds:g}s (log-mel + encoder + greedy decode)",
-        "value": round(audio_s / dt, 1), "unit": "audio-sec/wall-sec", "n_gpus": n_ranks, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak",
+        "metric": metric, "value": round(audio_s * args.steps / dt, 1), "unit": "audio-sec/wall-sec", "n_gpus": n_ranks,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "f32" if args.gemm == "f32" else "f32 (GEMMs: 3-term split on fp16 MFMA, fp32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": f"{args.model} (16-layer Conformer, random-init weights), {args.batch} x {args.seconds:g} s "
-                               f"16 kHz utterances per GPU, frontend+encoder+{'CTC' if is_ctc else 'RNN-T'} greedy, "
-                               "final all-gather of ids", "global_batch": args.batch * n_ranks,
-                   "audio_seconds_per_step": args.seconds * args.batch * n_ranks,
-                   "parallelism": f"dp{n_ranks} (utterance shards, RCCL all-gather of ids only)"},
-        "encoder_ms_per_utt": round(ms_step / args.batch, 4),
-        "tokens_decoded_per_step": int(sum(n_c)),
+        "config": {"workload": workload, "baseline_config": cfgno, "audio_seconds_per_step": round(audio_s, 1),
+                   "parallelism": f"dp{n_ranks} (utterance shards, replicated weights, one exchange: {gather_name})"},
     }
+    if n_units:
+        line["config"]["global_batch"] = n_units * (n_ranks if scaling == "weak" else 1)
+        line["encoder_ms_per_utt"] = round(ms_step / max(1, (g1 - g0)), 4)
+    if cfgno in (1, 2, 3):
+        line["tokens_decoded_per_step"] = int(sum(len(i) for i, _ in out))
+        decoded_mine = out[g0:g1] if n_ranks > 1 else out
+    else:
+        line["tokens_decoded_per_step"] = int(sum(len(r[0]) for r in out))
+        decoded_mine = None
+    if is_rnnt:
+        line["rnnt_blank_bias"] = bias
     if args.layers >= 0:
         line["INVALID"] = "debug run with --layers"
     if prof is not None:
-        fam = ("gemm", "conv2")  # one kernel template: gam_gemm_f32_kernel<ACT> (plain + implicit-GEMM stem conv)
-        flop = sum(prof[k]["work"] for k in fam)
-        ms = sum(prof[k]["ms"] for k in fam)
-        n = sum(prof[k]["launches"] for k in fam)
-        ach = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         if args.gemm == "f32":
             kern, peak, peak_note = "gam_gemm_f32_kernel (v_mfma_f32_32x32x2_f32; plain + implicit-GEMM conv)", FP32_MFMA_PEAK_TFLOPS, \
                 "fp32 dense MFMA peak"
@@ -222,15 +389,16 @@ def main():
             kern = ("gam_gemm_sp_kernel (LDS-DMA, sp32 operands; small GEMMs: gam_gemm_f16x3_kernel) -- 3x "
                     "v_mfma_f32_32x32x16_f16 per product; plain + implicit-GEMM conv")
             peak, peak_note = F16_MFMA_PEAK_TFLOPS / 3.0, "fp16 dense MFMA peak (2500) / 3 issued MFMA FLOP per algorithmic FLOP"
+        flop, ms, n, ach, frac = family(prof, peak)
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.gemm}.json")
-        if args.model == "v2_ctc" and args.batch == 32 and args.seconds == 20.0 and os.path.exists(tpath):
-            tj = json.load(open(tpath))       # committed rocprofv3 PMC passes of this same command
-            traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), os.path.relpath(tpath, ROOT)
+        if cfgno == 2 and args.batch == 32 and args.seconds == 20.0 and os.path.exists(tpath):
+            tj = json.load(open(tpath))       # committed rocprofv3 PMC passes of this same command (not re-measured in this run)
+            traffic, traffic_src = round(tj["traffic_bytes_per_launch"]), os.path.relpath(tpath, ROOT) + " (committed rocprofv3 --pmc passes of this command)"
         alg_bytes = sum(prof[k].get("bytes", 0.0) for k in fam)
         line["roofline"] = {
             "kernel": kern, "bound": "mfma", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-            "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+            "frac": round(frac, 4), "traffic": traffic, "traffic_source": traffic_src,
             "peak_note": peak_note, "issued_mfma_tflops": round(ach * (1.0 if args.gemm == "f32" else 3.0), 1),
             "algorithmic_bytes_per_launch": round(alg_bytes / max(1, n)),
             "launches_per_step": n // max(1, args.steps), "avg_launch_ms": round(ms / max(1, n), 4),
@@ -239,11 +407,28 @@ def main():
         }
         line["kernel_classes_ms_per_step"] = {k: round(v["ms"], 3) for k, v in prof_all.items() if v["launches"]}
         line["kernel_classes_note"] = "HIP-event time per class from one extra untimed step"
-        whole = FLOP_PER_UTT_20S_V2 * (args.seconds / 20.0) * args.batch * n_ranks / (ms_step * 1e-3) / 1e12
-        line["whole_path_tflops"] = round(whole, 2)
-    if n_ranks == 1 and args.cpu_utts > 0:
+        if cfgno in (2, 3):
+            whole = FLOP_PER_UTT_20S_V2 * (args.seconds / 20.0) * (g1 - g0) / (ms_step * 1e-3) / 1e12
+            line["whole_path_tflops_per_gpu"] = round(whole, 2)
+    if f32_leg is not None:
+        dt32, out32, p32 = f32_leg
+        leg = {"ms_per_step": round(dt32 / args.steps * 1e3, 3), "value": round(audio_s * args.steps / dt32, 1),
+               "unit": "audio-sec/wall-sec", "dtype": "f32 (v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fmaf chain)",
+               "ids_identical_to_default_mode": sum(a == b for a, b in zip(out32, out)), "utterances": len(out)}
+        if p32 is not None:
+            flop, ms, n, ach, frac = family(p32, FP32_MFMA_PEAK_TFLOPS)
+            leg.update(achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, frac=round(frac, 4), launches_per_step=n // max(1, args.steps),
+                       avg_launch_ms=round(ms / max(1, n), 4))
+        line["roofline_f32_exact"] = leg
+    n_cpu = args.cpu_utts if args.cpu_utts >= 0 else (32 if cfgno == 2 else 4)
+    if n_ranks == 1 and n_cpu > 0 and cpu_sample is not None:
         try:
-            line["cpu_baseline"] = cpu_baseline(ckpt, wav_h, wlen_h, min(args.cpu_utts, g1 - g0), decoded)
+            w_h, l_h, gidx = cpu_sample
+            if cfgno in (1, 2, 3):
+                gpu_dec = decoded_mine
+            else:
+                gpu_dec = [(out[g][0], out[g][1]) for g in gidx]
+            line["cpu_baseline"] = cpu_baseline(ckpt, w_h, l_h, min(n_cpu, w_h.shape[0]), gpu_dec, sweep=(cfgno == 2))
         except Exception as e:  # the bench line must still print
             line["cpu_baseline"] = {"error": repr(e)}
     print(json.dumps(line, ensure_ascii=False), flush=True)

@@ -59,6 +59,13 @@ SIGNATURES = {
     "gam_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "gam_profile_read_bytes": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     "gam_last_error": (C.c_char_p, [_P]),
+    # multi-GPU exchange (RCCL behind the boundary)
+    "gam_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "gam_comm_create": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(_P)]),
+    "gam_comm_world": (C.c_int, [_P]),
+    "gam_gather_ids": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "gam_comm_last_error": (C.c_char_p, [_P]),
+    "gam_comm_destroy": (None, [_P]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -16,6 +16,7 @@
 #include "../../include/gigaam_hip.h"
 #include "gam_attn.h"
 #include "gam_attn16.h"
+#include "gam_comm.h"
 #include "gam_common.h"
 #include "gam_convmod.h"
 #include "gam_decode.h"
@@ -1126,12 +1127,9 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
   ProfScope ps(h, s, GAM_PF_DECODE, 0.0);
   a.wout_in_lds = gam_rnnt_smem(a.H, a.JH, a.V, 1) <= 96 * 1024 ? 1 : 0;
   const size_t sm = gam_rnnt_smem(a.H, a.JH, a.V, a.wout_in_lds);
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gam_rnnt_greedy_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gam_rnnt_greedy_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr = true;
-  }
+  static std::atomic<unsigned long long> attr5{0}, attr8{0};
+  HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_rnnt_greedy_kernel<5>), 160 * 1024, attr5));
+  HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_rnnt_greedy_kernel<8>), 160 * 1024, attr8));
   if (sm > 160 * 1024) return fail(h, -1, "RNN-T head too large for the greedy kernel's LDS window");
   if (4 * a.H <= 256 * 5) hipLaunchKernelGGL(gam_rnnt_greedy_kernel<5>, dim3(B), dim3(256), sm, s, a);
   else hipLaunchKernelGGL(gam_rnnt_greedy_kernel<8>, dim3(B), dim3(256), sm, s, a);

@@ -11,6 +11,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int gam_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: set it once for every
+// device a launch site is used on (a process may hold handles on several GPUs).  `mask` is the
+// launch site's own bit set of devices already done; a failed call is reported, not swallowed.
+#include <atomic>
+static inline hipError_t gam_set_max_lds(const void* kern, int bytes, std::atomic<unsigned long long>& mask) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (mask.load(std::memory_order_acquire) & bit) return hipSuccess;
+  e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) mask.fetch_or(bit, std::memory_order_release);
+  return e;
+}
+
 __device__ __forceinline__ float gam_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -194,12 +194,8 @@ static inline hipError_t gam_launch_convmod(const GamConvModArgs& a, int layer_n
       hipLaunchKernelGGL(gam_convmod_ln_kernel<5>, grid, dim3(256), sm, s, a);
     } else if (a.ks == 31) {
       const size_t sm = ((8 + 30) * a.d + 32) * sizeof(float);
-      static bool attr = false;
-      if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gam_convmod_ln_kernel<31>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr = true;
-      }
+      static std::atomic<unsigned long long> attr_devs{0};
+      if (hipError_t e = gam_set_max_lds(reinterpret_cast<const void*>(gam_convmod_ln_kernel<31>), 160 * 1024, attr_devs)) return e;
       hipLaunchKernelGGL(gam_convmod_ln_kernel<31>, grid, dim3(256), sm, s, a);
     } else if (a.ks == 9) {
       const size_t sm = ((8 + 8) * a.d + 32) * sizeof(float);

@@ -279,12 +279,8 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 3 : 2) void gam_gemm_f32_kernel(Ga
 
 template <int ACT, int NBUF>
 static inline void gam_launch_gemm_t(const GamGemmArgs& a, int grid, hipStream_t stream) {
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gam_gemm_f32_kernel<ACT, NBUF>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, GAM_GEMM_SMEM(NBUF));
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> attr_devs{0};
+  if (gam_set_max_lds(reinterpret_cast<const void*>(gam_gemm_f32_kernel<ACT, NBUF>), GAM_GEMM_SMEM(NBUF), attr_devs) != hipSuccess) return;
   hipLaunchKernelGGL((gam_gemm_f32_kernel<ACT, NBUF>), dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(256), GAM_GEMM_SMEM(NBUF), stream, a);
 }
 

@@ -246,13 +246,10 @@ __global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : 3)) void gam_ge
 
 template <int ACT, int BM = 128, bool PIPE = false>
 static inline void gam_launch_gemm16_t(const GamGemmArgs& a, int grid, hipStream_t stream) {
-  static bool attr_done = false;
+  static std::atomic<unsigned long long> attr_devs{0};
   constexpr int smem = GamGemm16Cfg<32, BM>::SMEM * (PIPE ? 2 : 1);
   auto kern = gam_gemm_f16x3_kernel<ACT, BM, PIPE>;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_done = true;
-  }
+  if (gam_set_max_lds(reinterpret_cast<const void*>(kern), smem, attr_devs) != hipSuccess) return;   // the error stays latched for hipGetLastError()
   hipLaunchKernelGGL(kern, dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(2 * BM), smem, stream, a);
 }
 

@@ -319,13 +319,10 @@ static inline bool gam_gemm_sp_epilogue_ok(const GamGemmArgs& a) {
 
 template <int ACT, int MT, int NW>
 static inline void gam_launch_gemm_sp_t(const GamGemmArgs& a, int grid, hipStream_t stream) {
-  static bool attr_done = false;
+  static std::atomic<unsigned long long> attr_devs{0};
   constexpr int smem = GamGemmSpCfg<MT, NW>::SMEM;
   auto kern = gam_gemm_sp_kernel<ACT, MT, NW>;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    attr_done = true;
-  }
+  if (gam_set_max_lds(reinterpret_cast<const void*>(kern), smem, attr_devs) != hipSuccess) return;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * NW), smem, stream, a);
 }
 

@@ -1,0 +1,177 @@
+"""Multi-GPU sharding of the hot path: utterances are independent, so ranks own disjoint sets of
+utterances / batches, weights are replicated, and the ONLY exchange is the final gather of the decoded
+``(counts, ids, frames)``.  Host-side bookkeeping only -- which rank runs what, and how the gathered rows go back
+to the caller's order; the exchange itself is ``gam_gather_ids`` (RCCL, include/gigaam_hip.h) on GPUs, or any
+callable with the same contract (the world_size-2 gloo tests pass a torch.distributed one).
+
+The reference has no multi-GPU inference path (its loop is gigaam/model.py:219-258, one device); the layout the
+ranks assemble is the reference's collate layout (gigaam/utils.py:371-380) per batch.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+
+def shard_range(n_items: int, rank: int, n_ranks: int) -> Tuple[int, int]:
+    """Contiguous block of ceil(n/ranks) items per rank."""
+    per = (n_items + n_ranks - 1) // n_ranks
+    return min(n_items, rank * per), min(n_items, (rank + 1) * per)
+
+
+def sorted_batches(lengths: Sequence[int], batch_size: int) -> List[List[int]]:
+    """Indices sorted by length (longest first, ties by index) cut into consecutive batches: bounds the padding
+    of every batch by the length spread inside it."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    return [order[i:i + batch_size] for i in range(0, len(order), batch_size)]
+
+
+def deal(n_batches: int, rank: int, n_ranks: int, snake: bool = True) -> List[int]:
+    """Batch indices of ``rank``.  ``snake``: boustrophedon order (0..R-1, R-1..0, ...) so that with batches sorted
+    by cost every rank gets the same mix of long and short ones; otherwise plain round-robin."""
+    out = []
+    for j in range(n_batches):
+        r = j % n_ranks
+        if snake and (j // n_ranks) % 2 == 1:
+            r = n_ranks - 1 - r
+        if r == rank:
+            out.append(j)
+    return out
+
+
+def pack_results(rows: Sequence[Tuple[int, Sequence[int], Sequence[int]]], n_rows: int, cap: int):
+    """Local decode results [(global_index, ids, frames)] -> fixed-shape buffers for the gather:
+    index i32 [n_rows] (-1 = unused row), counts i32 [n_rows], ids / frames i32 [n_rows, cap]."""
+    index = torch.full((n_rows,), -1, dtype=torch.int32)
+    counts = torch.zeros((n_rows,), dtype=torch.int32)
+    ids = torch.zeros((n_rows, cap), dtype=torch.int32)
+    frames = torch.zeros((n_rows, cap), dtype=torch.int32)
+    assert len(rows) <= n_rows
+    for r, (g, i, f) in enumerate(rows):
+        n = len(i)
+        assert n <= cap and len(f) == n
+        index[r], counts[r] = g, n
+        ids[r, :n] = torch.as_tensor(list(i), dtype=torch.int32)
+        frames[r, :n] = torch.as_tensor(list(f), dtype=torch.int32)
+    return index, counts, ids, frames
+
+
+def unpack_results(index: Tensor, counts: Tensor, ids: Tensor, frames: Tensor, n_total: int):
+    """Gathered buffers (rank-major) -> [(ids, frames)] in global-index order; every index in [0, n_total) must
+    appear exactly once."""
+    index, counts, ids, frames = (t.cpu() for t in (index, counts, ids, frames))
+    out: List[Optional[Tuple[List[int], List[int]]]] = [None] * n_total
+    for r in range(index.shape[0]):
+        g = int(index[r])
+        if g < 0:
+            continue
+        if not 0 <= g < n_total or out[g] is not None:
+            raise RuntimeError(f"utterance {g} gathered twice or out of range")
+        n = int(counts[r])
+        out[g] = (ids[r, :n].tolist(), frames[r, :n].tolist())
+    missing = [g for g, o in enumerate(out) if o is None]
+    if missing:
+        raise RuntimeError(f"{len(missing)} utterances were never decoded (first: {missing[:5]})")
+    return out
+
+
+def run_sharded(batches: Sequence[Tuple[Tensor, Tensor, Sequence[int]]], decode_batch: Callable, rank: int, n_ranks: int,
+                gather: Callable, cap: int, snake: bool = True, my_batches: Optional[Sequence[int]] = None):
+    """Drive one rank's share of ``batches`` [(wav, len, global_indices)] through ``decode_batch(wav, len) ->
+    [(ids, frames)]`` and gather everything: returns [(ids, frames)] for ALL utterances in global order (on every
+    rank).  ``gather(index, counts, ids, frames) -> the same four, concatenated rank-major``; it is called exactly
+    once, after the last local batch -- the path's one exchange."""
+    mine = list(my_batches) if my_batches is not None else deal(len(batches), rank, n_ranks, snake)
+    n_total = sum(len(b[2]) for b in batches)
+    # every rank contributes the same number of rows (fixed-size all-gather): the largest share
+    per_rank = max(sum(len(batches[j][2]) for j in deal(len(batches), r, n_ranks, snake)) for r in range(n_ranks))
+    rows = []
+    for j in mine:
+        wav, wlen, gidx = batches[j]
+        res = decode_batch(wav, wlen)
+        assert len(res) == len(gidx)
+        rows += [(int(g), i, f) for g, (i, f) in zip(gidx, res)]
+    packed = pack_results(rows, per_rank, cap)
+    return unpack_results(*gather(*packed), n_total)
+
+
+# --------------------------------------------------------------------------- the exchange, through the C ABI
+class HipComm:
+    """``gam_comm`` (include/gigaam_hip.h): RCCL communicator behind the C ABI, one per rank.
+
+    ``exchange_id(id_bytes_or_None) -> id_bytes`` is how the 128-byte RCCL id travels from rank 0 to the others;
+    anything works (bench.py passes a torch.distributed broadcast, a reference-side binder could use a file)."""
+
+    def __init__(self, rank: int, world: int, device: torch.device, exchange_id: Callable[[Optional[bytes]], bytes]):
+        import ctypes as C
+
+        from . import _lib
+        self._C, self.lib = C, _lib.load_library()
+        self.rank, self.world = rank, world
+        self.device = torch.device(device)
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            rc = self.lib.gam_comm_unique_id(buf)
+            if rc != 0:
+                raise _lib.GigaAMHipError(f"gam_comm_unique_id failed ({rc}): {self.lib.gam_comm_last_error(None).decode()}")
+        uid = exchange_id(buf.raw if rank == 0 else None)
+        assert len(uid) == 128
+        self._c = C.c_void_p()
+        rc = self.lib.gam_comm_create(uid, rank, world, self.device.index or 0, C.byref(self._c))
+        self._check(rc, "gam_comm_create")
+
+    def _check(self, rc: int, what: str) -> None:
+        if rc != 0:
+            from ._lib import GigaAMHipError
+            msg = self.lib.gam_comm_last_error(self._c)
+            raise GigaAMHipError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+
+    def gather(self, index: Optional[Tensor], counts: Tensor, ids: Tensor, frames: Tensor):
+        """(index [rows] | None, counts [rows], ids [rows,cap], frames [rows,cap]) i32 on this rank's GPU ->
+        the same, concatenated rank-major over all ranks; asynchronous on torch's current stream."""
+        C = self._C
+        dev = self.device
+        cv = lambda t: None if t is None else t.to(device=dev, dtype=torch.int32).contiguous()  # noqa: E731
+        index, counts, ids, frames = cv(index), cv(counts), cv(ids), cv(frames)
+        rows, cap = ids.shape
+        w = self.world
+        a_index = None if index is None else torch.empty((w * rows,), dtype=torch.int32, device=dev)
+        a_counts = torch.empty((w * rows,), dtype=torch.int32, device=dev)
+        a_ids = torch.empty((w * rows, cap), dtype=torch.int32, device=dev)
+        a_frames = torch.empty((w * rows, cap), dtype=torch.int32, device=dev)
+        p = lambda t: C.c_void_p(0 if t is None else t.data_ptr())  # noqa: E731
+        with torch.cuda.device(dev):
+            rc = self.lib.gam_gather_ids(self._c, p(index), p(counts), p(ids), p(frames), rows, cap, p(a_index), p(a_counts),
+                                         p(a_ids), p(a_frames), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        self._check(rc, "gam_gather_ids")
+        return a_index, a_counts, a_ids, a_frames
+
+    def close(self) -> None:
+        if getattr(self, "_c", None):
+            self.lib.gam_comm_destroy(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def torch_gather(index: Optional[Tensor], counts: Tensor, ids: Tensor, frames: Tensor):
+    """The same exchange over an initialised torch.distributed group (gloo in the CPU tests; kept as bench.py's
+    ``--gather torch`` cross-check of the RCCL path).  World size 1: identity."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return index, counts, ids, frames
+    outs = []
+    for t in (index, counts, ids, frames):
+        if t is None:
+            outs.append(None)
+            continue
+        buf = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(buf, t.contiguous())
+        outs.append(torch.cat(buf, dim=0))
+    return tuple(outs)

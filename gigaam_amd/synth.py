@@ -327,19 +327,20 @@ def make_checkpoint(model_name: str, seed: int = 0, calib="auto", rnnt_blank_bia
 
 
 def synth_audio(batch: int, seconds: float, seed: int = 0, sample_rate: int = 16000,
-                lengths: Optional[List[int]] = None) -> tuple:
+                lengths: Optional[List[int]] = None, index0: int = 0) -> tuple:
     """Seeded synthetic utterances with speech-like time structure: a random
     sequence of 60-260 ms "syllables" (harmonic stacks with per-syllable pitch,
     spectral tilt and amplitude, some noisy, some silent) plus a noise floor;
     harmonic tones + noise + taper in the spirit of reference
     tests/test_batching.py:15-25.  Returns (wav f32 [B,L], len i64 [B]);
     samples beyond ``lengths[b]`` are zero (AudioDataset.collate layout,
-    reference gigaam/utils.py:371-380)."""
+    reference gigaam/utils.py:371-380).  Row ``b`` is utterance ``index0 + b`` of the seed's stream, so a rank
+    can generate its own slice of a global batch."""
     n = int(round(seconds * sample_rate))
     wav = np.zeros((batch, n), dtype=np.float32)
     lens = np.full((batch,), n, dtype=np.int64) if lengths is None else np.asarray(lengths, dtype=np.int64)
     for b in range(batch):
-        rng = np.random.Generator(np.random.PCG64([seed, b]))
+        rng = np.random.Generator(np.random.PCG64([seed, index0 + b]))
         lb = int(lens[b])
         sig = np.zeros(lb, dtype=np.float64)
         pos = 0

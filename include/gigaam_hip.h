@@ -152,6 +152,33 @@ int gam_profile_read(gam_handle* h, int cls, double* ms, int64_t* launches, doub
 /* algorithmic (unique operand + result) bytes of the timed launches of a GEMM class */
 int gam_profile_read_bytes(gam_handle* h, int cls, double* bytes);
 
+/* ---- multi-GPU: the path's ONE exchange -------------------------------------------------
+ * Utterances are independent, so ranks (one process per GPU) decode disjoint shards with replicated weights
+ * and never talk during the encoder; what is exchanged at the end are the fixed-shape decode buffers.  The
+ * reference has no multi-device inference loop (gigaam/model.py:219-258 runs on one device); a binder that
+ * shards that loop calls these three entry points.  Transport: RCCL (ncclAllGather over xGMI), resolved at
+ * run time with dlopen("librccl.so.1") -- inside a torch process that is the RCCL torch already loaded.
+ *
+ *   gam_comm_unique_id   rank 0 makes the 128-byte RCCL id; the caller ships it to the other ranks by any
+ *                        host channel it has (a file, MPI, torch.distributed's store, an environment variable)
+ *   gam_comm_create      every rank: ncclCommInitRank on `device_id`
+ *   gam_gather_ids       all-gather of index i32 [rows], counts i32 [rows], ids i32 [rows,cap], frames i32
+ *                        [rows,cap] (DEVICE pointers; every rank passes the same rows / cap) into
+ *                        all_* [world*rows ...], rank-major; one grouped RCCL call, asynchronous on `stream`.
+ *                        `index` carries each row's global utterance number (or -1 for an unused row) so the
+ *                        caller can restore its order; it may be NULL (then all_index must be NULL too).
+ */
+typedef struct gam_comm gam_comm;
+#define GAM_COMM_ID_BYTES 128
+int gam_comm_unique_id(char id_out[GAM_COMM_ID_BYTES]);
+int gam_comm_create(const char id[GAM_COMM_ID_BYTES], int rank, int world, int device_id, gam_comm** out);
+int gam_comm_world(const gam_comm* c);
+int gam_gather_ids(gam_comm* c, const int32_t* index, const int32_t* counts, const int32_t* ids, const int32_t* frames,
+                   int rows, int cap, int32_t* all_index, int32_t* all_counts, int32_t* all_ids, int32_t* all_frames,
+                   void* stream);
+const char* gam_comm_last_error(const gam_comm* c);
+void gam_comm_destroy(gam_comm* c);
+
 const char* gam_last_error(const gam_handle* h);
 
 #ifdef __cplusplus

@@ -30,7 +30,8 @@ from oracle.ref_shim import import_reference  # noqa: E402
 from make_golden import kw, strip  # noqa: E402
 
 N_UTT = 4
-BIASES = [16.0, 15.0, 17.0, 14.0, 18.0, 13.0, 19.0, 12.0, 20.0, 11.0]
+BIASES = [None, 7.0, 8.0, 9.0, 10.0, 11.0, 12.0, 14.0, 16.0, 18.0, 20.0, 22.0, 24.0]   # None = the synthetic head's default
+N_POOL = 12   # CTC: utterances examined; the N_UTT with the widest argmax margins are kept
 
 
 def audio_for(name):
@@ -38,7 +39,8 @@ def audio_for(name):
         wav, wlen = workloads.config4_batches(n_utts=1024, batch=32, only_batches=[0])[0][:2]
         return wav[:N_UTT].contiguous(), wlen[:N_UTT].contiguous()
     wav, wlen = workloads.config2_batch(32, 20.0, rank=0)
-    return wav[:N_UTT].contiguous(), wlen[:N_UTT].contiguous()
+    n = N_POOL if name.endswith("ctc") else N_UTT
+    return wav[:n].contiguous(), wlen[:n].contiguous()
 
 
 def main():
@@ -66,10 +68,16 @@ def main():
                 head = ref.decoder.CTCHead(**kw(cfg["head"])).eval()
                 head.load_state_dict(strip(sd, "head."))
                 dec = ref.decoding.CTCGreedyDecoding(cfg["decoding"]["vocabulary"])
-                r = dec.decode(head, y_ref, l_ref)
                 lp = head(y_ref)
                 top2 = lp.topk(2, dim=-1).values
-                st["min_margin"] = float((top2[..., 0] - top2[..., 1])[valid[:, 0, :]].min())
+                marg = torch.where(valid[:, 0, :], top2[..., 0] - top2[..., 1], torch.full_like(top2[..., 0], 1e9)).min(dim=1).values
+                keep = sorted(sorted(range(len(marg)), key=lambda i: -float(marg[i]))[:N_UTT])
+                print(name, "per-utterance min margins", [round(float(m), 5) for m in marg], "keep", keep, flush=True)
+                y_ref, l_ref, lp = y_ref[keep].contiguous(), l_ref[keep].contiguous(), lp[keep]
+                out.update(enc_len=l_ref.numpy(), enc_probe=y_ref[:, ::16, ::5].numpy(), wav_len=wlen[keep].numpy(),
+                           utt_index=np.asarray(keep, np.int32))
+                st.update(utt_index=keep, min_margin=float(marg[keep].min()), frames=l_ref.tolist())
+                r = dec.decode(head, y_ref, l_ref)
                 o = O.ctc_greedy(O.ctc_log_probs(sd, y_ref), l_ref)
             else:
                 v = cfg["head"]["decoder"]["num_classes"]
@@ -77,8 +85,9 @@ def main():
                 default_bias = float(sd["head.joint.joint_net.1.bias"][v - 1])
                 base = default_bias - (5.3 + 0.35 * np.log(v))
                 chosen = None
+                out["utt_index"] = np.arange(N_UTT, dtype=np.int32)
                 for bb in BIASES:
-                    sd["head.joint.joint_net.1.bias"][v - 1] = base + bb
+                    sd["head.joint.joint_net.1.bias"][v - 1] = default_bias if bb is None else base + bb
                     trace = []
                     o = O.rnnt_greedy(sd, y_ref, l_ref, ms, trace=trace)
                     marg = min(float(t[2].topk(2).values[0] - t[2].topk(2).values[1]) for t in trace)
@@ -87,14 +96,15 @@ def main():
                     if 0.1 <= spf <= 0.6 and marg > 2e-3 and min(len(a) for a, _ in o) > 3:
                         chosen = bb
                         break
-                assert chosen is not None, name
+                else:
+                    raise AssertionError(name)
                 ck2 = synth.make_checkpoint(model, seed=0, rnnt_blank_bias=chosen)
                 assert torch.equal(ck2["state_dict"]["head.joint.joint_net.1.bias"], sd["head.joint.joint_net.1.bias"])
                 head = ref.decoder.RNNTHead(cfg["head"]["decoder"], cfg["head"]["joint"]).eval()
                 head.load_state_dict(strip(sd, "head."))
                 dec = ref.decoding.RNNTGreedyDecoding(cfg["decoding"]["vocabulary"], max_symbols_per_step=ms)
                 r = dec.decode(head, y_ref, l_ref)
-                st.update(blank_bias=chosen, min_margin=marg, symbols_per_frame=round(spf, 3), joint_steps=len(trace))
+                st.update(blank_bias=chosen, utt_index=list(range(N_UTT)), min_margin=marg, symbols_per_frame=round(spf, 3), joint_steps=len(trace))
                 # top-4 log-probs of every joint step, per utterance in order (the full [steps, V] dump is too big to commit)
                 tv = torch.stack([t[2].topk(4).values for t in trace])
                 ti = torch.stack([t[2].topk(4).indices for t in trace])

@@ -1,9 +1,12 @@
-"""CPU, world_size 2 over gloo: the N>1 harness path of bench.py -- shard bookkeeping,
-the final gather of (counts, ids, frames) and the max-over-ranks timing reduction."""
+"""CPU, world_size 2 over gloo: the N>1 host logic of the hot path (gigaam_amd/shard.py) and of bench.py -- which rank
+decodes what, the single exchange of (index, counts, ids, frames), restoring the caller's order, and the max-over-ranks
+timing.  The decoders are fakes (a deterministic function of the audio), so what is under test is exactly the part
+that cannot be seen on one GPU: every utterance decoded exactly once, by exactly one rank, and back in order."""
 import os
 import socket
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -19,11 +22,39 @@ def _free_port():
     return p
 
 
+def fake_decode(wav, wlen):
+    """ids = a few numbers derived from the utterance's samples and length, frames = 0..n-1."""
+    out = []
+    for row, n in zip(wav, wlen.tolist()):
+        k = 1 + int(n) % 5
+        ids = [int(n) % 97, int(round(float(row[: int(n)].sum()) * 1000)) % 1009] + list(range(k))
+        out.append((ids, list(range(len(ids)))))
+    return out
+
+
+def _config4_like(n_utts, batch):
+    """Ragged set -> sorted batches with global indices, like workloads.config4_batches but tiny."""
+    from gigaam_amd.shard import sorted_batches
+    g = torch.Generator().manual_seed(5)
+    lens = torch.randint(20, 200, (n_utts,), generator=g).tolist()
+    audio = [torch.randn(n, generator=g) for n in lens]
+    batches = []
+    for idx in sorted_batches(lens, batch):
+        lmax = max(lens[i] for i in idx)
+        wav = torch.zeros(len(idx), lmax)
+        for r, i in enumerate(idx):
+            wav[r, : lens[i]] = audio[i]
+        batches.append((wav, torch.tensor([lens[i] for i in idx]), list(idx)))
+    return audio, lens, batches
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import bench
+    from gigaam_amd import shard
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    # (a) raw exchange + timing reduction
     tp, b = 7, 3
     counts = torch.tensor([2 + rank, 0, 5], dtype=torch.int32)
     ids = torch.full((b, tp), -1, dtype=torch.int32)
@@ -33,24 +64,79 @@ def _worker(rank, world, port, q):
         frames[i, :c] = torch.arange(c, dtype=torch.int32)
     g_counts, g_ids, g_frames = bench.gather_decoded(counts, ids, frames)
     tmax = bench.max_over_ranks(1.0 + rank)
-    q.put((rank, g_counts.tolist(), g_ids.tolist(), g_frames.tolist(), tmax, bench.shard_range(10, rank, world)))
+    # (b) config-4 style: sorted batches dealt (snake) to the ranks, one exchange, global order restored
+    audio, lens, batches = _config4_like(37, 4)
+    seen = []
+
+    def dec(wav, wlen):
+        seen.append(wlen.tolist())
+        return fake_decode(wav, wlen)
+    res4 = shard.run_sharded(batches, dec, rank, world, shard.torch_gather, cap=16)
+    n_decoded4 = sum(len(s) for s in seen)
+    # (c) config-5 style: file-order batches of 16 dealt round-robin, rows packed with their global index
+    segs = [torch.randn(30 + 7 * i) for i in range(41)]
+    fr_bs = 16
+    n_b = (len(segs) + fr_bs - 1) // fr_bs
+    mine = shard.deal(n_b, rank, world, snake=False)
+    rows = []
+    for j in mine:
+        chunk = segs[j * fr_bs:(j + 1) * fr_bs]
+        from gigaam_amd.feeder import collate
+        wav, wlen = collate(chunk)
+        for k, (i, f) in enumerate(fake_decode(wav, wlen)):
+            rows.append((j * fr_bs + k, i, f))
+    per_rank = max(sum(min(len(segs), (j + 1) * fr_bs) - j * fr_bs for j in shard.deal(n_b, r, world, snake=False)) for r in range(world))
+    res5 = shard.unpack_results(*shard.torch_gather(*shard.pack_results(rows, per_rank, 16)), len(segs))
+    q.put((rank, g_counts.tolist(), g_ids.tolist(), g_frames.tolist(), tmax, bench.shard_range(10, rank, world), res4, n_decoded4,
+           res5, len(rows)))
     dist.destroy_process_group()
 
 
-def test_gather_and_timing_world2():
+def test_sharding_gather_and_timing_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, counts, ids, frames, tmax, shard in res:
+    audio, lens, batches = _config4_like(37, 4)
+    want4 = [None] * 37
+    for wav, wlen, gidx in batches:
+        for g, r in zip(gidx, fake_decode(wav, wlen)):
+            want4[g] = r
+    from gigaam_amd.feeder import collate
+    segs = [torch.randn(30 + 7 * i) for i in range(41)]   # (only the lengths matter for the shape of the expectation)
+    for rank, counts, ids, frames, tmax, shard_r, res4, n4, res5, n5 in res:
         assert counts == [2, 0, 5, 3, 0, 5]            # rank-major order of the utterance shards
         assert ids[0][:2] == [0, 1] and ids[3][:3] == [10, 11, 12] and ids[5][:5] == [12, 13, 14, 15, 16]
         assert frames[2][:5] == [0, 1, 2, 3, 4]
         assert tmax == 2.0                              # MAX over ranks
+        assert res4 == want4                            # every rank holds ALL results, in the caller's order
+        assert len(res5) == 41 and all(len(i) == len(f) for i, f in res5)
     assert res[0][5] == (0, 5) and res[1][5] == (5, 10)
+    assert res[0][7] + res[1][7] == 37                  # each utterance decoded by exactly one rank ...
+    assert abs(res[0][7] - res[1][7]) <= 4              # ... and the snake deal balances the ranks
+    assert res[0][9] + res[1][9] == 41 and res[0][8] == res[1][8]
+
+
+def test_deal_and_pack_invariants():
+    from gigaam_amd import shard
+    for n_b, world in [(32, 8), (7, 2), (5, 8), (1, 1), (0, 2)]:
+        for snake in (True, False):
+            got = sorted(j for r in range(world) for j in shard.deal(n_b, r, world, snake))
+            assert got == list(range(n_b))
+    # the snake deal gives every rank the same total when costs fall linearly with the index
+    costs = [100 - j for j in range(32)]
+    sums = [sum(costs[j] for j in shard.deal(32, r, 8)) for r in range(8)]
+    assert max(sums) - min(sums) == 0
+    assert shard.sorted_batches([5, 9, 9, 1], 3) == [[1, 2, 0], [3]]
+    idx, cnt, ids, frames = shard.pack_results([(4, [7, 8], [0, 3]), (2, [], [])], 3, 5)
+    assert idx.tolist() == [4, 2, -1] and cnt.tolist() == [2, 0, 0] and ids[0, :2].tolist() == [7, 8]
+    with pytest.raises(RuntimeError, match="never decoded"):
+        shard.unpack_results(idx, cnt, ids, frames, 5)
+    with pytest.raises(RuntimeError, match="twice"):
+        shard.unpack_results(torch.tensor([1, 1]), torch.tensor([0, 0]), torch.zeros(2, 1, dtype=torch.int32), torch.zeros(2, 1, dtype=torch.int32), 2)

@@ -1,111 +1,24 @@
 #!/usr/bin/env python3
-"""The five BASELINE.json configurations on ONE MI355X, one JSON line each.
+"""The five BASELINE.json configurations on ONE MI355X, one JSON line each (bench.py --config N; the multi-GPU
+forms of the same commands are `torchrun --nproc-per-node N bench.py --gpus N --config N [--scaling strong]`).
 
-  1  v2_ctc, one 5 s clip                      (bench.py --batch 1 --seconds 5)
-  2  v2_ctc, 32 x 20 s                         (bench.py; the headline line)
-  3  v2_rnnt, 32 x 20 s, max_symbols 10        (bench.py --model v2_rnnt)
-  4  v3_e2e_rnnt (V = 1025), 128 utterances per GPU with durations U(5 s, 20 s), seed 1234,
-     sorted by length into 32-utterance batches
-  5  one hour of audio through transcribe_longform: synthetic speech regions (the stand-in for
-     pyannote), the reference's chunk packer (22 s / 15 s / 30 s / 0.2 s), batches of 16 through the
-     pinned double-buffered feeder
-
-Configs 1-3 are bench.py runs (same contract as the headline).  4 and 5 are timed here with the
-package API; weights are the seeded synthetic checkpoints, audio is the synthetic tone/noise recipe.
-Note on 3/4: the synthetic RNN-T heads are emission-heavy by construction (they exercise the
-max_symbols_per_step path); `tokens` is printed so the decode share can be read against it.
-
-    python tools/bench_configs.py [--only 4,5] [--out gpurun_out/configs.jsonl]
+    python tools/bench_configs.py [--only 1,3,4,5] [--out gpurun_out/configs.jsonl]
 """
 import argparse
 import json
 import os
 import subprocess
 import sys
-import tempfile
-import time
-import wave
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
-import gigaam_amd  # noqa: E402
-from gigaam_amd import synth  # noqa: E402
 
-
-def bench_py(extra):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-utts", "0", "--steps", "5", "--warmup", "2"] + extra,
-                         capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1]
-    return json.loads(out)
-
-
-def config4(dev, blank_bias=None):
-    ck = synth.make_checkpoint("v3_e2e_rnnt", seed=0, rnnt_blank_bias=blank_bias)
-    model = gigaam_amd.model_from_checkpoint(ck, dev)
-    rng = np.random.RandomState(1234)
-    durs = np.sort(rng.uniform(5.0, 20.0, size=128))[::-1]
-    batches = []
-    for i in range(0, 128, 32):
-        d = durs[i:i + 32]
-        lens = [int(x * 16000) for x in d]
-        wav, wlen = synth.synth_audio(32, float(d.max()), seed=4000 + i, lengths=lens)
-        batches.append((wav.to(dev), wlen.to(dev)))
-    for wav, wlen in batches[:1]:
-        model.transcribe_batch(wav, wlen)          # warm-up: workspace growth, first-launch costs
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n_tok = 0
-    for wav, wlen in batches:
-        res = model.transcribe_batch(wav, wlen)
-        n_tok += sum(len(t) for t, _ in res)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    audio = float(durs.sum())
-    frames = sum(int(x * 16000) // 160 // 4 for x in durs)
-    head = "default synthetic head" if blank_bias is None else f"synthetic head with blank bias {blank_bias:g}"
-    return {"config": 4 if blank_bias is None else "4b", "metric": "RTFx v3_e2e_rnnt 128 utts U(5,20)s in 4 sorted batches of 32 (frontend + encoder + RNN-T greedy + detokenise), " + head,
-            "symbols_per_encoder_frame": round(n_tok / max(1, frames), 2),
-            "value": round(audio / dt, 1), "unit": "audio-sec/wall-sec", "n_gpus": 1, "audio_seconds": round(audio, 1),
-            "wall_ms": round(dt * 1e3, 2), "ms_per_utt": round(dt * 1e3 / 128, 3), "decoded_chars": n_tok,
-            "note": "the RNN-T loop costs ~150 us per emitted symbol at V = 1025, so the rate is set by symbols per frame "
-                    "(a trained e2e model emits ~0.15 per frame; the default synthetic head ~9, the max_symbols cap is 10); "
-                    "inputs resident in HBM, includes the host-side detokenisation of the package API"}
-
-
-def config5(dev):
-    ck = synth.make_checkpoint("v2_ctc", seed=0)
-    model = gigaam_amd.model_from_checkpoint(ck, dev)
-    sr, total = 16000, 3600
-    rng = np.random.RandomState(7)
-    # speech regions: 2-12 s of speech separated by 0.3-1.5 s pauses (stand-in for the VAD output)
-    regions, t = [], 0.5
-    while t < total - 13:
-        d = float(rng.uniform(2.0, 12.0))
-        regions.append((round(t, 2), round(t + d, 2)))
-        t += d + float(rng.uniform(0.3, 1.5))
-    chunks = []
-    for i in range(0, total, 60):        # the tone/noise recipe, a minute at a time
-        w, _ = synth.synth_audio(1, 60.0, seed=7000 + i)
-        chunks.append((w[0].numpy() * 32767.0).astype(np.int16))
-    pcm = np.concatenate(chunks)
-    path = os.path.join(tempfile.gettempdir(), "gam_longform_1h.wav")
-    with wave.open(path, "wb") as wf:
-        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(sr); wf.writeframes(pcm.tobytes())
-    model.transcribe_longform(path, speech_regions=regions[:40])   # warm-up
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out = model.transcribe_longform(path, speech_regions=regions)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    os.remove(path)
-    speech = sum(e - s for s, e in regions)
-    return {"config": 5, "metric": "RTFx v2_ctc longform 1 h file (load wav + pack regions + batches of 16 via pinned feeder + CTC greedy)",
-            "value": round(total / dt, 1), "unit": "audio-sec/wall-sec", "n_gpus": 1, "audio_seconds": total,
-            "speech_seconds": round(speech, 1), "segments": len(out), "wall_ms": round(dt * 1e3, 1),
-            "note": "end to end on one GPU including reading the 115 MB PCM16 file and host-side packing; "
-                    "speech regions are synthetic (the reference uses pyannote's VAD, a gated third-party model)"}
+EXTRA = {
+    1: ["--config", "1", "--steps", "20", "--warmup", "5", "--no-profile"],
+    2: ["--config", "2", "--steps", "10", "--warmup", "3"],
+    3: ["--config", "3", "--steps", "10", "--warmup", "3"],
+    4: ["--config", "4", "--steps", "3", "--warmup", "1", "--no-profile"],
+    5: ["--config", "5", "--steps", "2", "--warmup", "1", "--no-profile"],
+}
 
 
 def main():
@@ -113,26 +26,19 @@ def main():
     ap.add_argument("--only", default="1,2,3,4,5")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "configs.jsonl"))
     args = ap.parse_args()
-    only = {int(x) for x in args.only.split(",")}
-    dev = torch.device("cuda:0")
-    lines = []
-    if 1 in only:
-        d = bench_py(["--batch", "1", "--seconds", "5", "--no-profile", "--steps", "20", "--warmup", "5"]); d["config"] = 1; lines.append(d)
-    if 2 in only:
-        d = bench_py([]); d["config"] = 2; lines.append(d)
-    if 3 in only:
-        d = bench_py(["--model", "v2_rnnt"]); d["config"] = 3; lines.append(d)
-    if 4 in only:
-        lines.append(config4(dev))
-        lines.append(config4(dev, blank_bias=18.0))
-    if 5 in only:
-        lines.append(config5(dev))
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
-        for d in lines:
+        for c in [int(x) for x in args.only.split(",")]:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + EXTRA[c], capture_output=True, text=True)
+            if r.returncode != 0:
+                print(f"config {c} failed:\n{r.stderr[-2000:]}")
+                continue
+            d = json.loads(r.stdout.strip().splitlines()[-1])
             f.write(json.dumps(d, ensure_ascii=False) + "\n")
-            print(json.dumps({k: d[k] for k in ("config", "metric", "value", "unit") if k in d} |
-                             {k: d[k] for k in ("ms_per_step", "wall_ms", "tokens_decoded_per_step", "decoded_chars", "segments") if k in d}))
+            f.flush()
+            keys = ("metric", "value", "ms_per_step", "tokens_decoded_per_step")
+            print(json.dumps({"config": c, **{k: d[k] for k in keys if k in d},
+                              "cpu": (d.get("cpu_baseline") or {}).get("gpu_ids_identical")}, ensure_ascii=False))
 
 
 if __name__ == "__main__":
