@@ -115,6 +115,8 @@ struct gam_handle {
   hipStream_t cap_stream = nullptr;   // private stream for captures (the caller's may be the legacy default stream)
   int* lens = nullptr;  // 4 * maxB ints: len0, len1, len2, enc_len
   int lens_cap = 0;
+  DevBuf rsbuf, op_rs;  // per-row 2^-e of the LayerNorm-produced GEMM operand currently in y / yr; gam_op_gemm's
+  int* range_flag = nullptr;   // device int: set when an unscaled sp32 tensor left fp16's range (gam_range_flag)
 
   // profiler
   int prof_on = 0;   // 0 off, 1 every launch, 2 GEMM family only
@@ -279,6 +281,8 @@ struct ProfScope {
 
 int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls = GAM_PF_GEMM, const W16* w16 = nullptr) {
   GamGemmArgs a = a_in;
+  a.range_flag = h->range_flag;
+  if (h->gemm_mode != GAM_GEMM_F16X3 || w16 == nullptr || w16->hi == nullptr) a.a_rs = nullptr;   // exact-fp32 path: A is never scaled
   ProfScope ps(h, s, cls, 2.0 * (double)a.M * (double)a.N * (double)a.K);
   if (ps.ev) {   // unique bytes: A (overlapping rows counted once), W, C (+ residual)
     const double abytes = a.a_mode == 0 ? ((double)(a.M - 1) * (double)std::min<long>(a.lda, a.K) + a.K) * 4.0
@@ -387,10 +391,11 @@ void gam_destroy(gam_handle* h) {
   hipSetDevice(h->device);
   for (void* p : h->owned) hipFree(p);
   DevBuf* bufs[] = {&h->wavp, &h->spec, &h->img, &h->c2, &h->xin, &h->y1, &h->x, &h->y, &h->yr, &h->hbuf,
-                    &h->qk, &h->vbuf, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes, &h->op_sp, &h->splitk_ws};
+                    &h->qk, &h->vbuf, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes, &h->op_sp, &h->splitk_ws, &h->rsbuf, &h->op_rs};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   if (h->lens) hipFree(h->lens);
+  if (h->range_flag) hipFree(h->range_flag);
   for (auto& e : h->prof_events) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (auto& g : h->graphs)
     if (g.second.exec) hipGraphExecDestroy(g.second.exec);
@@ -719,6 +724,8 @@ int gam_finalize(gam_handle* h) {
     UP(h->jn_out_w, wo->data);
     UP(h->jn_out_b, bo->data);
   }
+  HIPCHK(h, hipMalloc(&h->range_flag, 64));
+  HIPCHK(h, hipMemset(h->range_flag, 0, 64));
   h->staged.clear();
   h->finalized = true;
   return 0;
@@ -817,6 +824,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
   if (int r = ensure(h, h->ctx, (size_t)N * D)) return r;
   if (int r = ensure(h, h->ubuf, (size_t)N * 2 * D)) return r;
   if (int r = ensure(h, h->zbuf, (size_t)N * D)) return r;
+  if (int r = ensure(h, h->rsbuf, (size_t)N + 64)) return r;
 
   {
     ProfScope ps(h, s, GAM_PF_MISC, 0.0);
@@ -889,6 +897,10 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
   GamLnArgs ln;
   memset(&ln, 0, sizeof ln);
   ln.rows = N; ln.d = D; ln.ta = Ta; ln.dk = dk; ln.eps = 1e-5f; ln.rcos = h->rot_cos; ln.rsin = h->rot_sin;
+  ln.rope_rows = c.pos_emb_max_len;
+  // split-fp16 modes: every LayerNorm hands its GEMMs a per-row power-of-two scale (gam_row_scale)
+  float* const rs = h->gemm_mode == GAM_GEMM_F16X3 ? h->rsbuf.p : nullptr;
+  ln.rs = rs;
   if (nl > 0) {
     GamLnArgs a = ln;
     a.x = h->x.p; a.out1 = h->y.p; a.w1 = h->layers[0].ln_ff1_w; a.b1 = h->layers[0].ln_ff1_b;
@@ -900,7 +912,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     // --- FFN 1 (macaron half step) ---
     {
       GamGemmArgs g = gemm_args(h->y.p, D, L.ff1_w1, L.ff1_b1, h->hbuf.p, DFF, N, DFF, D);
-      sp_a(g); g.c_split = sp;
+      sp_a(g); g.c_split = sp; g.a_rs = rs;
       if (int r = gemm(h, s, g, GAM_ACT_SILU, GAM_PF_GEMM, &L.s_ff1_w1)) return r;
       GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff1_w2, L.ff1_b2, h->x.p, D, N, D, DFF);
       g2.R = h->x.p; g2.ldr = D; g2.alpha = 0.5f;
@@ -915,10 +927,10 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       if (int r = layernorm(h, s, a, rel ? 0 : 1)) return r;
       // rotary: q,k project the rotated copy, v the plain one; rel_pos: all three project y
       GamGemmArgs gq = gemm_args(rel ? h->y.p : h->yr.p, D, L.wqk, L.bqk, h->qk.p, 2 * D, N, 2 * D, D);
-      sp_a(gq);
+      sp_a(gq); gq.a_rs = rs;
       if (int r = gemm(h, s, gq, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wqk)) return r;
       GamGemmArgs gv = gemm_args(h->y.p, D, L.wv, L.bv, h->vbuf.p, D, N, D, D);
-      sp_a(gv);
+      sp_a(gv); gv.a_rs = rs;
       if (int r = gemm(h, s, gv, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wv)) return r;
       if (rel) {  // P = linear_pos(pos_emb) for relative positions -(T'-1) .. T'-1 (no bias)
         const float* pe0 = h->rel_pe + (size_t)(c.pos_emb_max_len - 1 - (Tv - 1)) * D;
@@ -949,12 +961,12 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       a.split1 = sp;
       if (int r = layernorm(h, s, a, 0)) return r;
       GamGemmArgs g1 = gemm_args(h->y.p, D, L.pw1_w, L.pw1_b, h->ubuf.p, 2 * D, N, 2 * D, D);
-      sp_a(g1);
+      sp_a(g1); g1.a_rs = rs;
       if (int r = gemm(h, s, g1, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_pw1)) return r;
       GamConvModArgs cm;
       cm.u = h->ubuf.p; cm.z = h->zbuf.p; cm.dw_w = L.dw_w; cm.dw_b = L.dw_b; cm.n_scale = L.cn_scale; cm.n_shift = L.cn_shift;
       cm.lens = len2; cm.B = B; cm.Ta = Ta; cm.Tv = Tv; cm.d = D; cm.ks = c.conv_kernel_size; cm.eps = 1e-5f;
-      cm.z_split = sp;
+      cm.z_split = sp; cm.range_flag = h->range_flag;
       {
         ProfScope ps(h, s, GAM_PF_CONVMOD, (double)N * D * 3 * 4.0);
         hipError_t e = gam_launch_convmod(cm, c.conv_norm_type == GAM_NORM_LAYER, s);
@@ -972,7 +984,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       a.split1 = sp;
       if (int r = layernorm(h, s, a, 0)) return r;
       GamGemmArgs g = gemm_args(h->y.p, D, L.ff2_w1, L.ff2_b1, h->hbuf.p, DFF, N, DFF, D);
-      sp_a(g); g.c_split = sp;
+      sp_a(g); g.c_split = sp; g.a_rs = rs;
       if (int r = gemm(h, s, g, GAM_ACT_SILU, GAM_PF_GEMM, &L.s_ff2_w1)) return r;
       GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff2_w2, L.ff2_b2, h->x.p, D, N, D, DFF);
       g2.R = h->x.p; g2.ldr = D; g2.alpha = 0.5f;
@@ -988,6 +1000,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
         a.split2 = sp;
         if (int r = layernorm(h, s, a, 2)) return r;
       } else {
+        a.rs = nullptr;   // the last norm_out feeds no GEMM
         if (int r = layernorm(h, s, a, 0)) return r;
       }
     }
@@ -1172,16 +1185,20 @@ int gam_op_gemm(gam_handle* h, const float* A, const float* W, const float* bias
   }
   W16 w16;
   w16.hi = (_Float16*)h->op_planes.p; w16.lo = w16.hi + count + 8; w16.inv = 1.0f;
+  // per-row power-of-two scale of A, as the LayerNorm kernels provide it inside the encoder
+  if (int r = ensure(h, h->op_rs, (size_t)M + 64)) return r;
+  hipLaunchKernelGGL(gam_rowscale_kernel, dim3(gam_cdiv(M, 4)), dim3(256), 0, s, A, h->op_rs.p, M, K, (long)K);
+  g.a_rs = h->op_rs.p;
   if (h->use_sp && K % 32 == 0 && N % 4 == 0 && M >= h->sp_min_m) {
     // sp32 operands by pre-passes (in the encoder the producing kernels write sp32 directly and the
     // weight planes are built at gam_finalize)
     const size_t wn = (size_t)N * K, an = (size_t)M * K;
     if (int r = ensure(h, h->op_sp, wn + 64)) return r;
     hipLaunchKernelGGL(gam_to_sp32_kernel, dim3((int)std::min<size_t>((wn / 4 + 255) / 256, 4096)), dim3(256), 0, s, W,
-                       (_Float16*)h->op_sp.p, wn / 4);
+                       (_Float16*)h->op_sp.p, wn / 4, (const float*)nullptr, K);
     if (int r = ensure(h, h->aplanes, an + 64)) return r;
     hipLaunchKernelGGL(gam_to_sp32_kernel, dim3((int)std::min<size_t>((an / 4 + 255) / 256, 8192)), dim3(256), 0, s, A,
-                       (_Float16*)h->aplanes.p, an / 4);
+                       (_Float16*)h->aplanes.p, an / 4, (const float*)h->op_rs.p, K);
     w16.sp = (_Float16*)h->op_sp.p;
     g.Asp = (const _Float16*)h->aplanes.p;
   }
@@ -1211,6 +1228,17 @@ int gam_set_gemm_mode(gam_handle* h, int mode) {
 }
 
 int gam_get_gemm_mode(const gam_handle* h) { return h ? h->gemm_mode : -1; }
+
+int gam_range_flag(gam_handle* h, int* flag_host, void* stream) {
+  if (!h || !flag_host) return -1;
+  if (!h->finalized) return fail(h, -1, "gam_range_flag before gam_finalize");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(h, hipMemcpyAsync(flag_host, h->range_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipMemsetAsync(h->range_flag, 0, sizeof(int), s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  return 0;
+}
 
 int gam_profile_enable(gam_handle* h, int on) {
   if (!h) return -1;

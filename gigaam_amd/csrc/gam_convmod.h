@@ -20,57 +20,89 @@ struct GamConvModArgs {
   int B, Ta, Tv, d, ks;
   float eps;
   int z_split;   // z in the sp32 GEMM-operand layout
+  int* range_flag;   // z_split: values beyond fp16's range set it (gam_common.h gam_range_note); may be null
 };
 
-// ---- BatchNorm variant: block = 64 channels x 64 frames ----
+// ---- BatchNorm variant: block = 64 channels x 128 frames, a thread owns 4 consecutive channels ----
+// HBM-bound (read [N,2d] + write [N,d]).  Round 1 ran at 3.2 TB/s with 4-byte loads, 2-byte sp32 stores and
+// 64-frame tiles (47 % halo at k = 31); here every global access is 16 bytes (a lane's 4 channels: f32x4 loads,
+// one 16-byte fp32 store or two 8-byte sp32 stores), the tile is 128 frames (23 % halo, L2-served), and all
+// ~20 loads of a thread are in flight before the first is used.  The depthwise taps run over a register window
+// (8 outputs read 8 + KS - 1 tile rows once); the KS x 64 weights sit in LDS as [k][channel] and are read
+// once per tap.  Per output the fmaf chain runs k = 0 .. KS-1 as before: bit-identical results.
 template <int KS>
-__global__ __launch_bounds__(256) void gam_convmod_bn_kernel(GamConvModArgs a) {
-  constexpr int TT = 64, PAD = (KS - 1) / 2, ROWS = TT + KS - 1;
-  __shared__ float tile[ROWS * 64];
+__global__ __launch_bounds__(256, 2) void gam_convmod_bn_kernel(GamConvModArgs a) {
+  constexpr int TT = 128, PAD = (KS - 1) / 2, ROWS = TT + KS - 1, OUT = TT / 16;
+  __shared__ f32x4 tile[ROWS * 16];   // [row][quad]: 256-byte rows; a 16-lane ds_read_b128 group covers one row
+  __shared__ f32x4 wl[KS * 16];       // [k][quad]
   const int tid = threadIdx.x;
-  const int cl = tid & 63, tg = tid >> 6;
-  const int b = blockIdx.z, c = blockIdx.y * 64 + cl, t0 = blockIdx.x * TT;
+  const int q = tid & 15, rg = tid >> 4;
+  const int b = blockIdx.z, c = blockIdx.y * 64 + q * 4, t0 = blockIdx.x * TT;
   int klen = a.lens[b];
   klen = klen < a.Tv ? klen : a.Tv;
   const size_t rowbase = (size_t)b * a.Ta;
-  // GLU'd input tile.  All loads of a thread go in flight together (clamped row, value masked
-  // afterwards): a loop of "if in range: load" keeps ONE load outstanding per thread and the
-  // kernel ran at 2.7 TB/s.
-  constexpr int NLD = (ROWS + 3) / 4;
-  float ua[NLD], ub[NLD];
+  // GLU'd input tile: row r of the tile is loaded by row group r % 16 (clamped row, value masked afterwards --
+  // a per-element "if in range: load" keeps one load outstanding per thread)
+  constexpr int NLD = (ROWS + 15) / 16;
+  f32x4 ua[NLD], ub[NLD];
 #pragma unroll
   for (int u = 0; u < NLD; ++u) {
-    const int t = t0 - PAD + tg + 4 * u;
+    const int t = t0 - PAD + rg + 16 * u;
     const int tc = t < 0 ? 0 : (t < a.Ta ? t : a.Ta - 1);
     const float* up = a.u + (rowbase + tc) * (size_t)(2 * a.d);
-    ua[u] = up[c];
-    ub[u] = up[a.d + c];
+    ua[u] = *reinterpret_cast<const f32x4*>(up + c);
+    ub[u] = *reinterpret_cast<const f32x4*>(up + a.d + c);
+  }
+  {   // weights [d][KS] -> wl[k][quad]: this thread stages taps k = rg + 16 i of its 4 channels
+#pragma unroll
+    for (int i = 0; i < (KS + 15) / 16; ++i) {
+      const int k = rg + 16 * i;
+      if (k < KS) wl[k * 16 + q] = (f32x4){a.dw_w[(size_t)c * KS + k], a.dw_w[(size_t)(c + 1) * KS + k],
+                                           a.dw_w[(size_t)(c + 2) * KS + k], a.dw_w[(size_t)(c + 3) * KS + k]};
+    }
   }
 #pragma unroll
   for (int u = 0; u < NLD; ++u) {
-    const int rr = tg + 4 * u;
+    const int rr = rg + 16 * u;
     const int t = t0 - PAD + rr;
-    if (rr < ROWS) tile[rr * 64 + cl] = (t >= 0 && t < klen) ? ua[u] * gam_sigmoid(ub[u]) : 0.f;
+    if (rr < ROWS) {
+      f32x4 g = {0.f, 0.f, 0.f, 0.f};
+      if (t >= 0 && t < klen)
+        g = (f32x4){ua[u].x * gam_sigmoid(ub[u].x), ua[u].y * gam_sigmoid(ub[u].y), ua[u].z * gam_sigmoid(ub[u].z),
+                    ua[u].w * gam_sigmoid(ub[u].w)};
+      tile[rr * 16 + q] = g;
+    }
   }
-  float w[KS];
-#pragma unroll
-  for (int k = 0; k < KS; ++k) w[k] = a.dw_w[(size_t)c * KS + k];
-  const float bias = a.dw_b[c], sc = a.n_scale[c], sh = a.n_shift[c];
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(a.dw_b + c);
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(a.n_scale + c);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(a.n_shift + c);
   __syncthreads();
-  // register sliding window: the 16 outputs of this thread read 16 + KS - 1 tile rows once
-  // (46 LDS reads instead of 16 x 31)
-  float win[16 + KS - 1];
+  f32x4 win[OUT + KS - 1];
 #pragma unroll
-  for (int r = 0; r < 16 + KS - 1; ++r) win[r] = tile[(tg * 16 + r) * 64 + cl];
+  for (int r = 0; r < OUT + KS - 1; ++r) win[r] = tile[(rg * OUT + r) * 16 + q];
+  f32x4 acc[OUT];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int t = t0 + tg * 16 + i;
-    float acc = 0.f;
+  for (int i = 0; i < OUT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < KS; ++k) acc = fmaf(w[k], win[i + k], acc);   // same order as before: bit-identical
-    acc += bias;
-    const float y = acc * sc + sh;
-    if (t < a.Ta) gam_store1(a.z, (rowbase + t) * (size_t)a.d, c, gam_silu(y), a.z_split);
+  for (int k = 0; k < KS; ++k) {
+    const f32x4 w = wl[k * 16 + q];
+#pragma unroll
+    for (int i = 0; i < OUT; ++i) {
+      acc[i].x = fmaf(w.x, win[i + k].x, acc[i].x);
+      acc[i].y = fmaf(w.y, win[i + k].y, acc[i].y);
+      acc[i].z = fmaf(w.z, win[i + k].z, acc[i].z);
+      acc[i].w = fmaf(w.w, win[i + k].w, acc[i].w);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < OUT; ++i) {
+    const int t = t0 + rg * OUT + i;
+    const f32x4 y = (acc[i] + bias) * sc + sh;
+    const float o0 = gam_silu(y.x), o1 = gam_silu(y.y), o2 = gam_silu(y.z), o3 = gam_silu(y.w);
+    if (t < a.Ta) {
+      if (a.z_split) gam_range_note(a.range_flag, o0, o1, o2, o3);
+      gam_store4(a.z, (rowbase + t) * (size_t)a.d, c, o0, o1, o2, o3, a.z_split);
+    }
   }
 }
 
@@ -181,7 +213,7 @@ __global__ __launch_bounds__(256) void gam_convmod_ln_kernel(GamConvModArgs a) {
 static inline hipError_t gam_launch_convmod(const GamConvModArgs& a, int layer_norm, hipStream_t s) {
   if (!layer_norm) {
     if (a.d % 64 != 0) return hipErrorInvalidValue;
-    dim3 grid(gam_cdiv(a.Ta, 64), a.d / 64, a.B);
+    dim3 grid(gam_cdiv(a.Ta, 128), a.d / 64, a.B);
     if (a.ks == 31) hipLaunchKernelGGL(gam_convmod_bn_kernel<31>, grid, dim3(256), 0, s, a);
     else if (a.ks == 5) hipLaunchKernelGGL(gam_convmod_bn_kernel<5>, grid, dim3(256), 0, s, a);
     else if (a.ks == 9) hipLaunchKernelGGL(gam_convmod_bn_kernel<9>, grid, dim3(256), 0, s, a);

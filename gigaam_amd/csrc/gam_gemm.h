@@ -66,6 +66,11 @@ struct GamGemmArgs {
   int ntiles;           // set by the launcher
   int dbg;              // experiment switches (GAM_SP_DBG), 0 in production
   float wscale_inv;     // 2^-wshift, applied to the accumulator in the epilogue
+  // split-fp16 modes: per-row pre-scale of the A operand (gam_common.h gam_row_scale).  a_rs[m] = 2^-e_m multiplies
+  // row m's accumulators in the epilogue; an sp32 A arrives already scaled by 2^e_m, an fp32 A is scaled while the
+  // 128x128 kernel splits it.  null = none (always null on the exact-fp32 path).
+  const float* a_rs;
+  int* range_flag;      // c_split outputs carry no row scale: values beyond fp16's range set this flag (may be null)
 };
 
 #define GAM_GEMM_BM 128
@@ -93,7 +98,8 @@ __device__ __forceinline__ void gam_gemm_epilogue(const GamGemmArgs& g, const f3
         for (int tn = 0; tn < 2; ++tn) {
           const int col = n0 + wn * 64 + tn * 32 + lcol;
           if (col < g.N)
-            P[(size_t)row * g.N + col] = (tm == 0 ? (tn == 0 ? acc00[r] : acc01[r]) : (tn == 0 ? acc10[r] : acc11[r])) * accscale;
+            P[(size_t)row * g.N + col] = (tm == 0 ? (tn == 0 ? acc00[r] : acc01[r]) : (tn == 0 ? acc10[r] : acc11[r])) *
+                                         (accscale * (g.a_rs != nullptr ? g.a_rs[row] : 1.0f));
         }
       }
     return;
@@ -114,11 +120,12 @@ __device__ __forceinline__ void gam_gemm_epilogue(const GamGemmArgs& g, const f3
           orow = (long)bb * g.out_rpb + tt + g.out_shift;
         }
       }
+      const float rowscale = accscale * (g.a_rs != nullptr ? g.a_rs[row] : 1.0f);
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
         const int col = n0 + wn * 64 + tn * 32 + lcol;
         if (col >= g.N) continue;
-        float v = (tm == 0 ? (tn == 0 ? acc00[r] : acc01[r]) : (tn == 0 ? acc10[r] : acc11[r])) * accscale;
+        float v = (tm == 0 ? (tn == 0 ? acc00[r] : acc01[r]) : (tn == 0 ? acc10[r] : acc11[r])) * rowscale;
         if (g.bias != nullptr) v += g.bias[col];
         if (ACT == GAM_ACT_SILU) v = gam_silu(v);
         if (ACT == GAM_ACT_RELU) v = fmaxf(v, 0.0f);

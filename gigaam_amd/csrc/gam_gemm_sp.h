@@ -291,7 +291,7 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
           orow = (long)bb * g.out_rpb + tt + g.out_shift;
         }
       }
-      v = v * accscale + bv;
+      v = v * (g.a_rs != nullptr ? accscale * g.a_rs[row] : accscale) + bv;
       if (ACT == GAM_ACT_SILU) { v.x = gam_silu(v.x); v.y = gam_silu(v.y); v.z = gam_silu(v.z); v.w = gam_silu(v.w); }
       if (ACT == GAM_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
       if (masked) v = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -301,6 +301,7 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
         _Float16* cp = reinterpret_cast<_Float16*>(g.C) + orow * (2 * g.ldc) + (ecol >> 5) * 64 + (ecol & 31);
         gam_half4 hi, lo;
         gam_split4(v, hi, lo);
+        gam_range_note(g.range_flag, v.x, v.y, v.z, v.w);
         *reinterpret_cast<gam_half4*>(cp) = hi;
         *reinterpret_cast<gam_half4*>(cp + 32) = lo;
       } else {
@@ -382,17 +383,33 @@ static inline hipError_t gam_launch_gemm_sp(const GamGemmArgs& a_in, int act, hi
   return hipGetLastError();
 }
 
-// fp32 [rows, K] (row pitch lda elements) -> sp32 (row pitch 2*lda halfs); 4 elements per thread
+// fp32 [rows, K] -> sp32 (row pitch 2*K halfs); 4 elements per thread.  rs (optional, [rows]): the row's 2^-e from
+// gam_rowscale_kernel -- the values are stored multiplied by 2^e (gam_common.h gam_row_scale).
 __global__ __launch_bounds__(256) void gam_to_sp32_kernel(const float* __restrict__ x, _Float16* __restrict__ y,
-                                                          size_t n4) {
+                                                          size_t n4, const float* __restrict__ rs, int K) {
   const size_t stride = (size_t)gridDim.x * 256;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    const size_t e = i * 4;                       // flat element index; 32-element blocks are row-aligned
+    if (rs != nullptr) v = v * (1.0f / rs[e / (size_t)K]);
     gam_half4 h, l;
     gam_split4(v, h, l);
-    const size_t e = i * 4;                       // flat element index; 32-element blocks are row-aligned
     _Float16* p = y + (e >> 5) * 64 + (e & 31);
     *reinterpret_cast<gam_half4*>(p) = h;
     *reinterpret_cast<gam_half4*>(p + 32) = l;
   }
+}
+
+// rs[row] = 2^-e with max|row| 2^e in [2^7, 2^8): one wave per row of an fp32 [rows, K] matrix (row pitch lda)
+__global__ __launch_bounds__(256) void gam_rowscale_kernel(const float* __restrict__ x, float* __restrict__ rs, int rows,
+                                                           int K, long lda) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * lda;
+  float m = 0.f;
+  for (int k = lane; k < K; k += 64) m = fmaxf(m, fabsf(xr[k]));
+  m = gam_wave_max(m);
+  float s_, inv_;
+  gam_row_scale(m, s_, inv_);
+  if (lane == 0) rs[row] = inv_;
 }

@@ -21,7 +21,22 @@ struct GamLnArgs {
   int rows, d, ta, dk;
   float eps;
   int split1, split2;   // write out1 / out2 in the sp32 GEMM-operand layout (gam_common.h)
+  // Per-row pre-scale of the GEMM operand this kernel produces (gam_row_scale): rs[row] = 2^-e is what the
+  // consuming GEMM multiplies its accumulators by.  MODE 0: out1; MODE 1: out1 AND out2 (one scale for the
+  // plain and the rotated copy); MODE 2: out2.  An sp32 output is stored scaled; an fp32 output is stored as
+  // is (the 128x128 GEMM applies the scale while it splits).  null = no scaling.
+  float* rs;
+  int rope_rows;        // rows of rcos / rsin (pos_emb_max_len): the stride-padding rows of a row block clamp to it
 };
+
+// max |v| of a row held as float4[GAM_LN_MAXJ] across a wave
+__device__ __forceinline__ float gam_ln_rowmax(const float4 (&v)[GAM_LN_MAXJ], int d, int lane) {
+  float m = 0.f;
+#pragma unroll
+  for (int j = 0; j < GAM_LN_MAXJ; ++j)
+    if ((j * 64 + lane) * 4 < d) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[j].x), fabsf(v[j].y))), fmaxf(fabsf(v[j].z), fabsf(v[j].w)));
+  return gam_wave_max(m);
+}
 
 __device__ __forceinline__ void gam_ln_row(float4 (&v)[GAM_LN_MAXJ], int d, int lane, float eps,
                                            const float* w, const float* b) {
@@ -67,20 +82,34 @@ __global__ __launch_bounds__(256) void gam_layernorm_kernel(GamLnArgs a) {
     v[j] = c < a.d ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   gam_ln_row(v, a.d, lane, a.eps, a.w1, a.b1);
+  float sc1 = 1.0f, sc2 = 1.0f;    // applied to the stored values of an sp32 output
+  if (MODE != 2 && a.rs != nullptr) {
+    float s_, inv_;
+    gam_row_scale(gam_ln_rowmax(v, a.d, lane), s_, inv_);
+    if (live && lane == 0) a.rs[row] = inv_;
+    if (a.split1) sc1 = s_;
+    if (a.split2) sc2 = s_;
+  }
   if (live) {
 #pragma unroll
     for (int j = 0; j < GAM_LN_MAXJ; ++j) {
       const int c = (j * 64 + lane) * 4;
-      if (c < a.d) gam_store4(a.out1, (size_t)row * a.d, c, v[j].x, v[j].y, v[j].z, v[j].w, a.split1);
+      if (c < a.d) gam_store4(a.out1, (size_t)row * a.d, c, v[j].x * sc1, v[j].y * sc1, v[j].z * sc1, v[j].w * sc1, a.split1);
     }
   }
   if (MODE == 2) {
     gam_ln_row(v, a.d, lane, a.eps, a.w2, a.b2);
+    if (a.rs != nullptr) {
+      float s_, inv_;
+      gam_row_scale(gam_ln_rowmax(v, a.d, lane), s_, inv_);
+      if (live && lane == 0) a.rs[row] = inv_;
+      if (a.split2) sc2 = s_;
+    }
     if (live) {
 #pragma unroll
       for (int j = 0; j < GAM_LN_MAXJ; ++j) {
         const int c = (j * 64 + lane) * 4;
-        if (c < a.d) gam_store4(a.out2, (size_t)row * a.d, c, v[j].x, v[j].y, v[j].z, v[j].w, a.split2);
+        if (c < a.d) gam_store4(a.out2, (size_t)row * a.d, c, v[j].x * sc2, v[j].y * sc2, v[j].z * sc2, v[j].w * sc2, a.split2);
       }
     }
   }
@@ -92,7 +121,8 @@ __global__ __launch_bounds__(256) void gam_layernorm_kernel(GamLnArgs a) {
       if (c < a.d) *reinterpret_cast<float4*>(rb + c) = v[j];
     }
     __syncthreads();
-    const int t = row % a.ta;
+    int t = row % a.ta;
+    t = t < a.rope_rows ? t : a.rope_rows - 1;   // stride-padding rows past pos_emb_max_len are don't-care frames
     const int half = a.dk >> 1;
     const float* cs = a.rcos + (size_t)t * half;
     const float* sn = a.rsin + (size_t)t * half;
@@ -117,7 +147,7 @@ __global__ __launch_bounds__(256) void gam_layernorm_kernel(GamLnArgs a) {
           o[0] = self4.x * c4.x + oth4.x * s4.x; o[1] = self4.y * c4.y + oth4.y * s4.y;
           o[2] = self4.z * c4.z + oth4.z * s4.z; o[3] = self4.w * c4.w + oth4.w * s4.w;
         }
-        if (live) gam_store4(a.out2, (size_t)row * a.d, c, o[0], o[1], o[2], o[3], a.split2);
+        if (live) gam_store4(a.out2, (size_t)row * a.d, c, o[0] * sc2, o[1] * sc2, o[2] * sc2, o[3] * sc2, a.split2);
       }
     }
   }

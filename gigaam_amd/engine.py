@@ -140,6 +140,14 @@ class HipEngine:
     def gemm_mode(self) -> str:
         return {_lib.GEMM_F32: "f32", _lib.GEMM_F16X3: "f16x3"}[self.lib.gam_get_gemm_mode(self._h)]
 
+    def range_flag(self) -> bool:
+        """True if, since the last call, an unscaled split-fp16 GEMM operand left fp16's range (gam_range_flag);
+        synchronises the current stream and clears the flag."""
+        out = C.c_int(0)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.gam_range_flag(self._h, C.byref(out), self._stream()), "gam_range_flag")
+        return bool(out.value)
+
     def feat_frames(self, n_samples: int) -> int:
         return int(self.lib.gam_feat_frames(self._h, n_samples))
 

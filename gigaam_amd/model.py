@@ -92,7 +92,20 @@ class GigaAM(nn.Module):
         """wav [B,L], len [B] -> encoded [B,d_model,T'], len i32 [B]  (model.py:27-37;
         the reference wraps the encoder in fp16 autocast on GPU, this path stays fp32)."""
         features, feature_lengths = self.preprocessor(features, feature_lengths)
-        return self.encoder(features, feature_lengths)
+        out = self.encoder(features, feature_lengths)
+        eng = getattr(self.encoder, "engine", None)
+        if eng is not None and eng.gemm_mode == "f16x3" and eng.range_flag():
+            # an activation outside fp16's range reached a split-fp16 GEMM operand (include/gigaam_hip.h,
+            # gam_range_flag): the batch is repeated on the exact-fp32 MFMA path, which has no such limit
+            import warnings
+            warnings.warn("gigaam_amd: activation beyond the split-fp16 GEMM range; this batch was recomputed with "
+                          "GAM_GEMM_F32 (set GAM_GEMM_MODE=f32 to use that path throughout)", RuntimeWarning, stacklevel=2)
+            eng.set_gemm_mode("f32")
+            try:
+                out = self.encoder(features, feature_lengths)
+            finally:
+                eng.set_gemm_mode("f16x3")
+        return out
 
     @property
     def _device(self) -> torch.device:

@@ -127,6 +127,12 @@ int gam_emo_probs(gam_handle* h, const float* encoded, const int32_t* enc_len, i
  * The CTC / RNN-T head GEMMs always use GAM_GEMM_F32; gam_op_gemm follows the mode. */
 enum { GAM_GEMM_F32 = 0, GAM_GEMM_F16X3 = 1 };
 int gam_set_gemm_mode(gam_handle* h, int mode);
+/* Range guard of GAM_GEMM_F16X3.  LayerNorm-produced operands carry a per-row power-of-two scale and cannot leave
+ * fp16's range; the other GEMM inputs (FFN hidden, conv-module output, stem activations) are split as they are, and a
+ * value beyond +-60000 there sets a device flag instead of silently becoming inf.  gam_range_flag copies the flag
+ * accumulated since the last call to *flag_host (host int), clears it, and SYNCHRONISES `stream`; a caller that
+ * sees 1 should repeat the batch under GAM_GEMM_F32 (the Python shim does).  Always 0 under GAM_GEMM_F32. */
+int gam_range_flag(gam_handle* h, int* flag_host, void* stream);
 int gam_get_gemm_mode(const gam_handle* h);
 
 /* Raw GEMM entry for kernel-level tests and the roofline bench (arithmetic = current mode):

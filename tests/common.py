@@ -16,11 +16,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 from cases import CASES, EMO_CASE, RNNT_MIN_MARGIN, make_case_checkpoint  # noqa: E402  (shared with make_golden.py)
 
 # tolerances (fp32 vs fp32, different summation orders)
-TOL_FEAT = 2e-3      # log-mel, natural-log units
+TOL_FEAT = 5e-4      # log-mel, natural-log units (measured on the GPU, r02: 1.5e-4)
 # Mel bands more than 60 dB below their frame's strongest band are differences of large DFT terms: there an
 # fp32 DFT-by-matmul (this path) and an fp32 FFT (torch.stft, the oracle and the reference) legitimately
 # disagree by a few 1e-3 in the log (both are ~1e-6 relative to the frame norm); the bar there is looser.
-TOL_FEAT_WEAK = 2e-2
+TOL_FEAT_WEAK = 1e-2   # (measured: 3.7e-3)
 WEAK_BAND_DB = 60.0
 
 

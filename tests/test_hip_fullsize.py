@@ -111,8 +111,8 @@ def test_fullsize_config2_ctc_matches_reference():
     enc, elen = eng.encode(*eng.frontend(wav, wlen))
     assert elen.cpu().tolist() == gold["enc_len"].tolist()
     err = float((enc.cpu()[:, ::16, ::5] - torch.from_numpy(gold["enc_probe"])).abs().max())
-    report("fullsize_encoder_vs_reference", case="fullsize_v2_ctc", err=err, tol=1e-3, min_margin=meta["min_margin"])
-    assert err < 1e-3, err
+    report("fullsize_encoder_vs_reference", case="fullsize_v2_ctc", err=err, tol=2e-4, min_margin=meta["min_margin"])
+    assert err < 2e-4, err   # measured 8e-6 (r02)
     assert ragged_from_device(*eng.ctc_greedy(enc, elen)) == _ref_ragged(gold)
 
 
@@ -126,8 +126,8 @@ def test_fullsize_rnnt_matches_reference(name):
     enc, elen = eng.encode(*eng.frontend(wav, wlen))
     assert elen.cpu().tolist() == gold["enc_len"].tolist()
     err = float((enc.cpu()[:, ::16, ::5] - torch.from_numpy(gold["enc_probe"])).abs().max())
-    report("fullsize_encoder_vs_reference", case=name, err=err, tol=1e-3, min_margin=meta["min_margin"])
-    assert err < 1e-3, err
+    report("fullsize_encoder_vs_reference", case=name, err=err, tol=2e-4, min_margin=meta["min_margin"])
+    assert err < 2e-4, err   # measured 8e-6 (r02)
     tc = gold["trace_counts"].tolist()
     ids, frames, counts, dump, dcount = eng.rnnt_greedy(enc, elen, ms, dump_cap=max(tc))
     assert ragged_from_device(ids, frames, counts) == _ref_ragged(gold)

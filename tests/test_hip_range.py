@@ -1,0 +1,108 @@
+"""GPU: the split-fp16 GEMM mode outside the O(1) activation range it was tuned on.
+
+LayerNorm-produced operands carry a per-row power-of-two scale (gam_common.h gam_row_scale), so rows of any
+magnitude keep 22 significant bits; operands that cannot be scaled in advance raise the range flag and the Python
+shim repeats the batch on the exact-fp32 path."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from common import TOL_ENC, load_case, oracle_features, report, valid_mask
+from test_hip_parity import _make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f16x3-sp"])
+def test_gemm_rows_of_any_magnitude(mode):
+    """gam_op_gemm with every row of A at its own scale 2^-12 .. 2^+12 (and beyond fp16's range: 2^17): the error
+    bar is the usual 2e-5, relative to each ROW's largest output."""
+    from gigaam_amd import synth
+    eng = _make_engine(synth.model_cfg("v2_ctc"), {}, mode, head=False)
+    g = torch.Generator().manual_seed(7)
+    for (m, n, k) in [(300, 200, 64), (1000, 768, 768), (4016, 1536, 768)]:
+        a = torch.randn(m, k, generator=g)
+        e = torch.randint(-12, 13, (m, 1), generator=g).float()
+        e[::7] = 17.0      # rows far beyond 65504
+        e[3::11] = -20.0   # rows whose fp16 image would be all subnormals
+        a = a * torch.exp2(e)
+        w = torch.randn(n, k, generator=g) / k ** 0.5
+        b = torch.randn(n, generator=g)
+        ref = a.double() @ w.double().t() + b.double()
+        out = eng.op_gemm(a, w, b, 0).cpu().double()
+        rowmax = ref.abs().max(dim=1, keepdim=True).values.clamp(min=1.0)
+        err = float(((out - ref).abs() / rowmax).max())
+        report("gemm_row_range", mode=mode, m=m, n=n, k=k, rel_err=err, tol=2e-5)
+        assert bool(torch.isfinite(out).all()) and err < 2e-5, (mode, m, n, k, err)
+    assert not eng.range_flag()
+
+
+def _rescaled_checkpoint(ck, s):
+    """The same function with every pre-GEMM LayerNorm's gain and bias multiplied by 2^s and the consuming weight
+    matrices by 2^-s: bit-for-bit the same network in exact arithmetic (powers of two), but the GEMM A operands are
+    2^s times larger."""
+    sd = {k: v.clone() for k, v in ck["state_dict"].items()}
+    up, dn = 2.0 ** s, 2.0 ** -s
+    nl = ck["cfg"]["encoder"]["n_layers"]
+    for i in range(nl):
+        p = f"encoder.layers.{i}."
+        for ln, consumers in [("norm_feed_forward1", ["feed_forward1.linear1"]), ("norm_feed_forward2", ["feed_forward2.linear1"]),
+                              ("norm_conv", ["conv.pointwise_conv1"]),
+                              ("norm_self_att", ["self_attn.linear_q", "self_attn.linear_k", "self_attn.linear_v"])]:
+            sd[p + ln + ".weight"] *= up
+            sd[p + ln + ".bias"] *= up
+            for c in consumers:
+                sd[p + c + ".weight"] *= dn
+    return {"cfg": ck["cfg"], "state_dict": sd}
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f16x3-sp"])
+@pytest.mark.parametrize("s", [-14, -12, -6, 6, 12, 14])
+def test_encoder_layernorm_gain_range(mode, s):
+    """2-layer encoder with LayerNorm gains 2^s (compensated in the next weights): the output must stay within the
+    usual 2e-4 of the reference golden of the UNSCALED model -- at s = +14 the operands (|y| up to ~8e4) are beyond
+    fp16's range, at s = -14 they sit in its subnormals; the per-row scale makes both irrelevant."""
+    ck, wav, wlen, gold = load_case("v2_ctc_l2")
+    eng = _make_engine(ck["cfg"], _rescaled_checkpoint(ck, s)["state_dict"], mode)
+    feat_o, flen_o = oracle_features(ck, wav, wlen)
+    enc, elen = eng.encode(feat_o, flen_o)
+    vm = valid_mask(enc.shape[2], gold["enc_len"])
+    err = float(((enc.cpu() - torch.from_numpy(gold["encoded"])) * vm[:, None, :]).abs().max())
+    report("encoder_ln_gain_range", mode=mode, s=s, err=err, tol=TOL_ENC)
+    assert bool(torch.isfinite(enc).all()) and err < TOL_ENC, (mode, s, err)
+    assert not eng.range_flag()
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f16x3-sp"])
+def test_range_flag_and_fp32_fallback(mode):
+    """An operand that cannot be scaled in advance (the SiLU'd FFN hidden, written by a GEMM epilogue) beyond fp16's
+    range: the library raises the flag instead of producing inf, and the model shim recomputes the batch in exact
+    fp32 with a warning -- the result still matches the reference golden."""
+    import gigaam_amd
+    ck, wav, wlen, gold = load_case("v2_ctc_l2")
+    sd = {k: v.clone() for k, v in ck["state_dict"].items()}
+    for i in range(ck["cfg"]["encoder"]["n_layers"]):     # hidden * 2^16, undone by linear2: the same function
+        p = f"encoder.layers.{i}.feed_forward1."
+        sd[p + "linear1.weight"] *= 2.0 ** 16
+        sd[p + "linear1.bias"] *= 2.0 ** 16
+        sd[p + "linear2.weight"] *= 2.0 ** -16
+    # (SiLU is not homogeneous: the oracle of the modified network is the reference here)
+    from oracle import gigaam_oracle as O
+    feat_o, flen_o = oracle_features(ck, wav, wlen)
+    with torch.no_grad():
+        want, _ = O.encoder_forward(sd, ck["cfg"]["encoder"], feat_o, flen_o)
+    eng = _make_engine(ck["cfg"], sd, mode)
+    enc, _ = eng.encode(feat_o, flen_o)
+    assert eng.range_flag() and not eng.range_flag()       # raised, then cleared by the read
+    model = gigaam_amd.model_from_checkpoint({"cfg": ck["cfg"], "state_dict": sd}, "cuda:0")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        enc2, elen2 = model.forward(wav.to("cuda:0"), wlen.to("cuda:0"))
+    assert any("recomputed" in str(x.message) for x in w)
+    assert model.encoder.engine.gemm_mode == "f16x3"
+    vm = valid_mask(enc2.shape[2], gold["enc_len"])
+    err = float(((enc2.cpu() - want) * vm[:, None, :]).abs().max())
+    report("range_fallback", mode=mode, err=err)
+    assert err < 2e-3, err     # (whole path incl. the HIP frontend; the bar of smoke())

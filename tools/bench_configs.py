@@ -33,7 +33,11 @@ def main():
             if r.returncode != 0:
                 print(f"config {c} failed:\n{r.stderr[-2000:]}")
                 continue
-            d = json.loads(r.stdout.strip().splitlines()[-1])
+            js = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if not js:
+                print(f"config {c}: no JSON line\n{r.stdout[-1000:]}\n{r.stderr[-1000:]}")
+                continue
+            d = json.loads(js[-1])
             f.write(json.dumps(d, ensure_ascii=False) + "\n")
             f.flush()
             keys = ("metric", "value", "ms_per_step", "tokens_decoded_per_step")
