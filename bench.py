@@ -165,6 +165,8 @@ def rnnt_bias_for(model_name: str, override):
 def ragged_host(ids, frames, counts):
     """Decoded buffers -> host lists: the blocking D2H + slicing of gigaam_amd.decoding._ragged."""
     n = counts.cpu().tolist()
+    if n and min(n) < 0:
+        raise RuntimeError("decode reported a failed cluster hand-off (counts = -1)")
     width = max(n) if n else 0
     ih, fh = ids[:, :width].cpu(), frames[:, :width].cpu()
     return [(ih[i, :c].tolist(), fh[i, :c].tolist()) for i, c in enumerate(n)]

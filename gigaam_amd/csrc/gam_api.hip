@@ -20,6 +20,7 @@
 #include "gam_common.h"
 #include "gam_convmod.h"
 #include "gam_decode.h"
+#include "gam_decode_cluster.h"
 #include "gam_frontend.h"
 #include "gam_gemm.h"
 #include "gam_gemm16.h"
@@ -95,6 +96,9 @@ struct gam_handle {
   float *emo_w = nullptr, *emo_b = nullptr;
   float *jn_enc_w = nullptr, *jn_enc_b = nullptr, *jn_pred_t = nullptr, *jn_pred_b = nullptr;
   float *jn_out_w = nullptr, *jn_out_b = nullptr, *lstm_whh_t = nullptr, *lstm_tab = nullptr;
+  float *lstm_whh_q = nullptr, *jn_pred_q = nullptr;   // [k/4][row][4] re-layouts for the cluster decode kernel
+  int rnnt_cluster = -1;        // GAM_RNNT_CLUSTER: 0 = one workgroup per utterance, N = force N per utterance, -1 = auto
+  DevBuf rnnt_x;                // hand-off granules + status word of the cluster kernel
 
   // workspace (grow-only)
   DevBuf wavp, spec, img, c2, xin, y1, x, y, yr, hbuf, qk, vbuf, ctx, ubuf, zbuf, tok, logits, encp, pbuf, aplanes;
@@ -369,6 +373,7 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   if (const char* e = getenv("GAM_SP_MIN_M")) h->sp_min_m = atoi(e);
   if (const char* e = getenv("GAM_SPLITK")) h->use_splitk = atoi(e);
   if (const char* e = getenv("GAM_GRAPH")) h->use_graph = atoi(e);
+  if (const char* e = getenv("GAM_RNNT_CLUSTER")) h->rnnt_cluster = atoi(e);
   if (const char* e = getenv("GAM_GEMM_MODE")) h->gemm_mode = (strcmp(e, "f32") == 0) ? GAM_GEMM_F32 : GAM_GEMM_F16X3;
   const gam_config& c = h->cfg;
   if (c.d_model <= 0 || c.n_heads <= 0 || c.d_model % c.n_heads != 0)
@@ -391,7 +396,7 @@ void gam_destroy(gam_handle* h) {
   hipSetDevice(h->device);
   for (void* p : h->owned) hipFree(p);
   DevBuf* bufs[] = {&h->wavp, &h->spec, &h->img, &h->c2, &h->xin, &h->y1, &h->x, &h->y, &h->yr, &h->hbuf,
-                    &h->qk, &h->vbuf, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes, &h->op_sp, &h->splitk_ws, &h->rsbuf, &h->op_rs};
+                    &h->qk, &h->vbuf, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes, &h->op_sp, &h->splitk_ws, &h->rsbuf, &h->op_rs, &h->rnnt_x};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   if (h->lens) hipFree(h->lens);
@@ -715,6 +720,13 @@ int gam_finalize(gam_handle* h) {
       for (int k = 0; k < PH; ++k) whh_t[(size_t)k * 4 * PH + r] = whh->data[(size_t)r * PH + k];
     for (int r = 0; r < JH; ++r)
       for (int k = 0; k < PH; ++k) wp_t[(size_t)k * JH + r] = wp->data[(size_t)r * PH + k];
+    std::vector<float> whh_q((size_t)PH * 4 * PH), wp_q((size_t)PH * JH);
+    for (int r = 0; r < 4 * PH; ++r)
+      for (int k = 0; k < PH; ++k) whh_q[((size_t)(k / 4) * 4 * PH + r) * 4 + (k & 3)] = whh->data[(size_t)r * PH + k];
+    for (int r = 0; r < JH; ++r)
+      for (int k = 0; k < PH; ++k) wp_q[((size_t)(k / 4) * JH + r) * 4 + (k & 3)] = wp->data[(size_t)r * PH + k];
+    UP(h->lstm_whh_q, whh_q);
+    UP(h->jn_pred_q, wp_q);
     UP(h->lstm_tab, tab);
     UP(h->lstm_whh_t, whh_t);
     UP(h->jn_pred_t, wp_t);
@@ -1138,6 +1150,48 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
   a.dump = logits_dump; a.dump_count = dump_count; a.B = B; a.Tp = (int)Tp; a.V = c.num_classes; a.H = c.pred_hidden; a.JH = JH;
   a.max_symbols = max_symbols; a.cap = (int)Tp * max_symbols; a.dump_cap = logits_dump ? dump_cap : 0;
   ProfScope ps(h, s, GAM_PF_DECODE, 0.0);
+  // Cluster decode (gam_decode_cluster.h): C workgroups per utterance, grid <= one workgroup per CU.
+  // (8 utterance columns, one per XCD; C members of a cluster share an XCD.)
+  {
+    const int nu8 = gam_cdiv(B, 8);
+    int C = 256 / (8 * nu8);
+    C = C > 8 ? 8 : C;
+    if (h->rnnt_cluster >= 0) C = h->rnnt_cluster < C ? h->rnnt_cluster : C;
+    if (C >= 1 && JH % 4 == 0 && a.H % 4 == 0) {
+      GamRnntClusterArgs ca;
+      ca.a = a; ca.whh_q = h->lstm_whh_q; ca.wpred_q = h->jn_pred_q; ca.C = C;
+      const int nI = gam_cdiv(a.H, C), need = gam_cdiv(4 * nI, 256);
+      const int nr = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 3 ? 3 : (need <= 5 ? 5 : 8)));
+      const int nV = gam_cdiv(gam_cdiv(a.V, C), 16) * 16;
+      ca.wout_slice_in_lds = (size_t)nV * (JH + 4) * 4 + gam_rnnt_cluster_smem(a.H, JH, a.V, C, nr, 0) <= 96 * 1024 ? 1 : 0;
+      const size_t sm = gam_rnnt_cluster_smem(a.H, JH, a.V, C, nr, ca.wout_slice_in_lds);
+      const size_t xg = gam_rnnt_cluster_xgranules(a.H, JH, C) * (size_t)B;
+      if (sm <= 160 * 1024 && need <= 8) {
+        if (int r = ensure(h, h->rnnt_x, xg * 2 + 64)) return r;   // (floats: 2 per granule) + status word
+        HIPCHK(h, hipMemsetAsync(h->rnnt_x.p, 0, (xg * 2 + 64) * sizeof(float), s));
+        ca.xbuf = reinterpret_cast<unsigned long long*>(h->rnnt_x.p);
+        ca.status = reinterpret_cast<int*>(h->rnnt_x.p + xg * 2);
+        const dim3 grid(8 * nu8 * C);
+        static std::atomic<unsigned long long> at1{0}, at2{0}, at3{0}, at5{0}, at8{0};
+#define GAM_RC_LAUNCH(NRV, AT)                                                                                             \
+  {                                                                                                                        \
+    HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<NRV>), 160 * 1024, AT));               \
+    hipLaunchKernelGGL(gam_rnnt_cluster_kernel<NRV>, grid, dim3(256), sm, s, ca);                                          \
+  }
+        switch (nr) {
+          case 1: GAM_RC_LAUNCH(1, at1); break;
+          case 2: GAM_RC_LAUNCH(2, at2); break;
+          case 3: GAM_RC_LAUNCH(3, at3); break;
+          case 5: GAM_RC_LAUNCH(5, at5); break;
+          default: GAM_RC_LAUNCH(8, at8); break;
+        }
+#undef GAM_RC_LAUNCH
+        HIPCHK(h, hipGetLastError());
+        return 0;
+      }
+    }
+  }
+  // fallback: one workgroup per utterance (GAM_RNNT_CLUSTER=0, or shapes the cluster kernel does not take)
   a.wout_in_lds = gam_rnnt_smem(a.H, a.JH, a.V, 1) <= 96 * 1024 ? 1 : 0;
   const size_t sm = gam_rnnt_smem(a.H, a.JH, a.V, a.wout_in_lds);
   static std::atomic<unsigned long long> attr5{0}, attr8{0};

@@ -1,0 +1,415 @@
+// gam_decode_cluster.h -- RNN-T greedy decode with a CLUSTER of workgroups per utterance.
+//   reference: gigaam/decoding.py:128-207 (loop), decoder.py:85-102 (predict), :41-47 (joint)
+//
+// The one-workgroup-per-utterance kernel (gam_decode.h) is bound by what ONE CU can pull out of L2 per
+// step: W_hh (4H x H fp32 = 1.6 MB), W_pred (0.4 MB) and, for SentencePiece vocabularies, W_out
+// (V x JH = 1.3 MB) -- 65 us (V = 34) to 150 us (V = 1025) per emitted symbol, on 32 of 256 CUs.
+// Here C workgroups (C = 8 at 32 utterances: the whole chip) share one utterance:
+//   * member c owns H/C hidden units (all four gate rows of each, so the cell update is local), JH/C rows of
+//     W_pred and V/C classes of W_out: every weight byte is read by exactly one CU per step, 16 bytes per lane
+//     ([k/4][row][4] re-layout built at gam_finalize);
+//   * three all-gathers per emission inside the cluster -- h' (H floats), W_pred.h' (JH floats) and the
+//     per-frame (max, argmax, sum-exp) of each member's class slice -- and one per all-blank window.  The
+//     control flow (frame pointer, symbol count, label) is replicated: every member takes the same decisions
+//     from the same gathered values, so no control messages exist.
+//   * hand-off: data-tagged 8-byte granules {f32 payload, u32 tag} written and polled with relaxed agent-scope
+//     atomics (sc1, L1-bypassing; MI355X_MICROARCH.md "handoff-1to1": ~1 us).  The tag is the utterance's
+//     exchange counter, buffers alternate by parity, so a granule is never rewritten before every member has
+//     read it (an all-gather cannot complete before all members have written, i.e. finished the previous one).
+//   * every spin is bounded (wall clock): a member that gives up sets the launch's status word, its cluster
+//     unwinds, and counts[b] = -1 tells the host (the Python shim raises) -- a workgroup that was not resident
+//     cannot hang the GPU.  The launcher sizes the grid to <= one workgroup per CU.
+// Same arithmetic per (frame, state) as the single-workgroup kernel: gate sums run k = 0..H-1 in order, the
+// 16-frame joint window is the same v_mfma_f32_16x16x4_f32 product.
+#pragma once
+#include "gam_decode.h"
+
+struct GamRnntClusterArgs {
+  GamRnntArgs a;
+  const float* whh_q;        // [H/4][4H][4]   W_hh: element (row r, k) at ((k/4)*4H + r)*4 + k%4
+  const float* wpred_q;      // [H/4][JH][4]   joint.pred weight, same re-layout
+  unsigned long long* xbuf;  // per utterance: 2 x (H + JH + C*48) granules
+  int* status;               // != 0: a hand-off timed out somewhere in this launch
+  int C;                     // workgroups per utterance
+  int wout_slice_in_lds;     // this member's class slice of W_out is cached in LDS
+};
+
+#define GAM_RC_WIN 16
+#define GAM_RC_TIMEOUT_TICKS 100000000LL   // wall_clock64 ticks (100 MHz): 1 s
+
+__device__ __forceinline__ void gam_rc_put(unsigned long long* p, float v, unsigned tag) {
+  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+// poll one granule until its tag matches; false on timeout / launch-wide abort
+__device__ __forceinline__ bool gam_rc_get(const unsigned long long* p, unsigned tag, float& v, int* status) {
+  long long t_end = 0;
+  for (unsigned spin = 0;; ++spin) {
+    const unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(g >> 32) == tag) { v = __uint_as_float((unsigned)g); return true; }
+    if ((spin & 255u) == 255u) {
+      const long long now = wall_clock64();
+      if (t_end == 0) t_end = now + GAM_RC_TIMEOUT_TICKS;
+      if (now > t_end || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        atomicOr(status, 1);
+        return false;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+static inline size_t gam_rnnt_cluster_smem(int H, int JH, int V, int C, int nr, int wout_slice_in_lds) {
+  const int nV = ((V + C - 1) / C + 15) / 16 * 16;
+  size_t f = (size_t)4 * H + 256 * (size_t)nr + JH + 1024 + (size_t)GAM_RC_WIN * (JH + 4) + (size_t)GAM_RC_WIN * (nV + 1) + 64 +
+             (size_t)C * 48 + 16;
+  if (wout_slice_in_lds) f += (size_t)nV * (JH + 4);
+  return sizeof(float) * f;
+}
+__host__ __device__ static inline size_t gam_rnnt_cluster_xgranules(int H, int JH, int C) { return 2 * ((size_t)H + JH + (size_t)C * 48); }
+
+template <int NR>   // gate-row slots per thread: 4 * ceil(H / C) <= 256 * NR
+__global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float gam_smem_rc[];
+  const GamRnntArgs& a = g.a;
+  const int C = g.C;
+  // block -> (utterance, member): the members of a cluster sit on one XCD (block b runs on XCD b % 8), for
+  // speed only -- the hand-off is agent-scope and placement-independent
+  const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+  const int b = (slot / C) * 8 + xcd, cm = slot % C;
+  if (b >= a.B) return;   // (whole clusters drop out together)
+  const int H = a.H, JH = a.JH, V = a.V, blank = a.V - 1;
+  const int nI = (H + C - 1) / C, i0 = cm * nI, i1 = i0 + nI < H ? i0 + nI : H;        // my hidden units
+  const int nP = (JH + C - 1) / C, r0 = cm * nP, r1 = r0 + nP < JH ? r0 + nP : JH;     // my rows of W_pred
+  const int nV = ((V + C - 1) / C + 15) / 16 * 16, v0 = cm * nV, v1 = v0 + nV < V ? v0 + nV : V;   // my classes
+  const int ZLD = JH + 4, LLD = nV + 1, WLD = JH + 4;
+
+  float* h_s = gam_smem_rc;               // committed h (all H)
+  float* hn_s = h_s + H;                  // candidate h' (all H)
+  float* c_s = hn_s + H;                  // committed c of my units [nI]
+  float* cn_s = c_s + H;                  // candidate c' of my units
+  float* gates = cn_s + H;                // [256 * NR] my gate rows, slot = gate * nI + unit
+  float* pp = gates + 256 * NR;           // W_pred.h' + b_pred (all JH)
+  float* red = pp + JH;                   // [1024] partial sums of the W_pred slice
+  float* zw = red + 1024;                 // [WIN][ZLD]  relu(enc + pred)   (offset is a multiple of 4 floats)
+  float* lgw = zw + GAM_RC_WIN * ZLD;     // [WIN][LLD]  logits of my classes
+  int* lab_s = reinterpret_cast<int*>(lgw + GAM_RC_WIN * LLD);   // [WIN]
+  float* lse_s = reinterpret_cast<float*>(lab_s + GAM_RC_WIN);   // [WIN]
+  int* dead_s = reinterpret_cast<int*>(lse_s + GAM_RC_WIN);      // [1] (+ padding to 64)
+  float* apart = lse_s + GAM_RC_WIN + 32;                        // [C][WIN][3]  (max, argmax bits, sum-exp)
+  float* wout_l = g.wout_slice_in_lds ? apart + C * 48 : nullptr;   // [nV][WLD] (every segment above is a multiple of 16 bytes)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg4 = lane >> 4;
+  int len = a.enc_len[b];
+  len = len < 0 ? 0 : (len > a.Tp ? a.Tp : len);
+
+  unsigned long long* xh = g.xbuf + (size_t)b * gam_rnnt_cluster_xgranules(H, JH, C);   // [2][H]
+  unsigned long long* xp = xh + 2 * H;                                                  // [2][JH]
+  unsigned long long* xa = xp + 2 * JH;                                                 // [2][C][WIN][3]
+
+  for (int i = tid; i < H; i += 256) { h_s[i] = 0.f; c_s[i] = 0.f; }
+  if (tid == 0) dead_s[0] = 0;
+  if (wout_l != nullptr)
+    for (int i = tid; i < (v1 > v0 ? v1 - v0 : 0) * JH; i += 256) wout_l[(i / JH) * WLD + (i % JH)] = a.wout[(size_t)v0 * JH + i];
+  __syncthreads();
+
+  // my gate-row slots: slot s = tid + 256 j -> gate s / nI, unit i0 + s % nI
+  int grow[NR];
+  bool gok[NR];
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const int s = tid + 256 * j, gi = s / nI, ii = s - gi * nI;
+    gok[j] = gi < 4 && i0 + ii < i1;
+    grow[j] = gok[j] ? gi * H + i0 + ii : 0;
+  }
+  // W_pred slice: P k-parts per row when the slice is small
+  const int P = nP >= 128 ? 1 : (256 / nP < 8 ? 256 / nP : 8);
+  const int HQ = H / 4, JQ = JH / 4;
+
+  int label = V;       // gate_tab row V: zero embedding (predict(None, None), decoder.py:97-100)
+  int n_out = 0, n_dump = 0;
+  int t = 0, sym = 0;
+  bool need_pred = true;
+  unsigned xc = 0;     // exchange counter = tag
+  int par_h = 0, par_p = 0, par_a = 0;
+  bool dead = false;
+
+  while (t < len && !dead) {
+    if (need_pred) {
+      // ---- LSTM gates of my units: tab[label] + W_hh.h, k ascending (same fmaf chain as the 1-workgroup kernel)
+      {
+        float acc[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[j] = a.gate_tab[(size_t)label * 4 * H + grow[j]];
+        constexpr int KU = NR == 1 ? 16 : (NR == 2 ? 8 : 4);   // float4 loads in flight per row slot
+        for (int q0 = 0; q0 < HQ; q0 += KU) {
+          f32x4 w[KU][NR];
+#pragma unroll
+          for (int u = 0; u < KU; ++u) {
+            const int q = q0 + u < HQ ? q0 + u : HQ - 1;
+#pragma unroll
+            for (int j = 0; j < NR; ++j) w[u][j] = *reinterpret_cast<const f32x4*>(g.whh_q + ((size_t)q * 4 * H + grow[j]) * 4);
+          }
+#pragma unroll
+          for (int u = 0; u < KU; ++u) {
+            if (q0 + u < HQ) {
+              const f32x4 hv = *reinterpret_cast<const f32x4*>(h_s + 4 * (q0 + u));
+#pragma unroll
+              for (int j = 0; j < NR; ++j) {
+                acc[j] = fmaf(w[u][j].x, hv.x, acc[j]);
+                acc[j] = fmaf(w[u][j].y, hv.y, acc[j]);
+                acc[j] = fmaf(w[u][j].z, hv.z, acc[j]);
+                acc[j] = fmaf(w[u][j].w, hv.w, acc[j]);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+          if (gok[j]) gates[tid + 256 * j] = acc[j];
+      }
+      __syncthreads();
+      ++xc;
+      for (int ii = tid; i0 + ii < i1; ii += 256) {   // cell update of my units (gate order i, f, g, o)
+        const float ig = gam_sigmoid_exact(gates[ii]), fg = gam_sigmoid_exact(gates[nI + ii]);
+        const float gg = tanhf(gates[2 * nI + ii]), og = gam_sigmoid_exact(gates[3 * nI + ii]);
+        const float cn = fg * c_s[ii] + ig * gg;
+        const float hn = og * tanhf(cn);
+        cn_s[ii] = cn;
+        if (C > 1) gam_rc_put(xh + par_h * H + i0 + ii, hn, xc);
+        else hn_s[i0 + ii] = hn;
+      }
+      if (C > 1) {
+        for (int i = tid; i < H; i += 256) {
+          float v;
+          if (!gam_rc_get(xh + par_h * H + i, xc, v, g.status)) { dead_s[0] = 1; v = 0.f; }
+          hn_s[i] = v;
+        }
+        par_h ^= 1;
+      }
+      __syncthreads();
+      if (dead_s[0]) { dead = true; break; }
+      // ---- my rows of W_pred.h' + b_pred
+      {
+        if (P == 1) {
+          for (int rr = tid; r0 + rr < r1; rr += 256) {
+            const int r = r0 + rr;
+            float acc = a.bpred[r];
+            for (int q0 = 0; q0 < HQ; q0 += 8) {
+              f32x4 w[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const f32x4*>(g.wpred_q + ((size_t)(q0 + u < HQ ? q0 + u : HQ - 1) * JH + r) * 4);
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+                if (q0 + u < HQ) {
+                  const f32x4 hv = *reinterpret_cast<const f32x4*>(hn_s + 4 * (q0 + u));
+                  acc = fmaf(w[u].x, hv.x, acc); acc = fmaf(w[u].y, hv.y, acc); acc = fmaf(w[u].z, hv.z, acc); acc = fmaf(w[u].w, hv.w, acc);
+                }
+            }
+            red[rr] = acc;
+          }
+        } else {
+          const int rr = tid % nP, part = tid / nP;
+          if (part < P && r0 + rr < r1) {
+            const int r = r0 + rr;
+            const int qa = part * HQ / P, qb = (part + 1) * HQ / P;
+            float acc = part == 0 ? a.bpred[r] : 0.f;
+            for (int q0 = qa; q0 < qb; q0 += 8) {
+              f32x4 w[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const f32x4*>(g.wpred_q + ((size_t)(q0 + u < qb ? q0 + u : qb - 1) * JH + r) * 4);
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+                if (q0 + u < qb) {
+                  const f32x4 hv = *reinterpret_cast<const f32x4*>(hn_s + 4 * (q0 + u));
+                  acc = fmaf(w[u].x, hv.x, acc); acc = fmaf(w[u].y, hv.y, acc); acc = fmaf(w[u].z, hv.z, acc); acc = fmaf(w[u].w, hv.w, acc);
+                }
+            }
+            red[part * nP + rr] = acc;
+          }
+        }
+      }
+      __syncthreads();
+      ++xc;
+      for (int rr = tid; r0 + rr < r1; rr += 256) {
+        float v = red[rr];
+        for (int p = 1; p < P; ++p) v += red[p * nP + rr];
+        if (C > 1) gam_rc_put(xp + par_p * JH + r0 + rr, v, xc);
+        else pp[r0 + rr] = v;
+      }
+      if (C > 1) {
+        for (int i = tid; i < JH; i += 256) {
+          float v;
+          if (!gam_rc_get(xp + par_p * JH + i, xc, v, g.status)) { dead_s[0] = 1; v = 0.f; }
+          pp[i] = v;
+        }
+        par_p ^= 1;
+      }
+      need_pred = false;
+      __syncthreads();
+      if (dead_s[0]) { dead = true; break; }
+    }
+
+    // ---- joint of frames t .. t+W-1 with the current predictor state: z = relu(enc + pred) (all JH, every member)
+    const int W = len - t < GAM_RC_WIN ? len - t : GAM_RC_WIN;
+    for (int i0z = 0; i0z < GAM_RC_WIN * JQ; i0z += 256 * 4) {
+      f32x4 ze[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int idx = i0z + tid + 256 * u;
+        idx = idx < GAM_RC_WIN * JQ ? idx : GAM_RC_WIN * JQ - 1;
+        const int f = idx / JQ, q = idx - f * JQ;
+        const int tt = t + (f < W ? f : W - 1);
+        ze[u] = *reinterpret_cast<const f32x4*>(a.encp + ((size_t)b * a.Tp + tt) * JH + 4 * q);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = i0z + tid + 256 * u;
+        if (idx < GAM_RC_WIN * JQ) {
+          const int f = idx / JQ, q = idx - f * JQ;
+          const f32x4 pv = *reinterpret_cast<const f32x4*>(pp + 4 * q);
+          *reinterpret_cast<f32x4*>(zw + f * ZLD + 4 * q) =
+              (f32x4){fmaxf(ze[u].x + pv.x, 0.f), fmaxf(ze[u].y + pv.y, 0.f), fmaxf(ze[u].z + pv.z, 0.f), fmaxf(ze[u].w + pv.w, 0.f)};
+        }
+      }
+    }
+    __syncthreads();
+    // logits[f][v] = bout[v] + sum_k z[f][k] wout[v][k] for my classes: one 16x16 MFMA tile per 16 classes
+    for (int nt = wave; v0 + nt * 16 < v1; nt += 4) {
+      const int v = v0 + nt * 16 + li;
+      const int vc = v < V ? v : V - 1;
+      const float* wr = (wout_l != nullptr ? wout_l + (size_t)(vc - v0) * WLD : a.wout + (size_t)vc * JH) + 4 * lg4;
+      const float* zr = zw + li * ZLD + 4 * lg4;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int k0 = 0; k0 + 64 <= JH; k0 += 64) {
+        float4 wf[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const float4*>(wr + k0 + 16 * u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float4 zf = *reinterpret_cast<const float4*>(zr + k0 + 16 * u);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.x, wf[u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf[u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf[u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf[u].w, acc, 0, 0, 0);
+        }
+      }
+      for (int k0 = JH / 64 * 64; k0 + 16 <= JH; k0 += 16) {
+        const float4 zf = *reinterpret_cast<const float4*>(zr + k0);
+        const float4 wf = *reinterpret_cast<const float4*>(wr + k0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.x, wf.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf.w, acc, 0, 0, 0);
+      }
+      if (v < v1) {   // C/D: col = lane&15 = class, row = 4*(lane>>4) + r = frame
+        const float bo = a.bout[v];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lgw[(4 * lg4 + r) * LLD + (v - v0)] = acc[r] + bo;
+      }
+    }
+    __syncthreads();
+    // per-frame (max, first argmax, sum-exp) over my classes: wave w takes frames w, w+4, ...
+    ++xc;
+    for (int f = wave; f < GAM_RC_WIN; f += 4) {
+      const float* lr = lgw + f * LLD;
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+      if (f < W)
+        for (int vl = lane; v0 + vl < v1; vl += 64) {
+          const float x = lr[vl];
+          if (x > best || (x == best && v0 + vl < bi)) { best = x; bi = v0 + vl; }
+        }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      float se = 0.f;
+      if (a.dump != nullptr && f < W && v1 > v0) {
+        for (int vl = lane; v0 + vl < v1; vl += 64) se += expf(lr[vl] - best);
+        se = gam_wave_sum(se);
+      }
+      if (lane == 0) {
+        if (C > 1) {
+          unsigned long long* q = xa + (((size_t)par_a * C + cm) * GAM_RC_WIN + f) * 3;
+          gam_rc_put(q + 0, best, xc);
+          gam_rc_put(q + 1, __int_as_float(bi), xc);
+          gam_rc_put(q + 2, se, xc);
+        } else {
+          apart[f * 3 + 0] = best; apart[f * 3 + 1] = __int_as_float(bi); apart[f * 3 + 2] = se;
+        }
+      }
+    }
+    if (C > 1) {
+      for (int i = tid; i < C * GAM_RC_WIN * 3; i += 256) {
+        float v;
+        if (!gam_rc_get(xa + (size_t)par_a * C * GAM_RC_WIN * 3 + i, xc, v, g.status)) { dead_s[0] = 1; v = 0.f; }
+        apart[i] = v;
+      }
+      par_a ^= 1;
+    }
+    __syncthreads();
+    if (dead_s[0]) { dead = true; break; }
+    if (tid < GAM_RC_WIN) {   // combine the members' slices (ascending class order: the first maximum wins)
+      const int f = tid;
+      float M = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int c = 0; c < C; ++c) {
+        const float m = apart[(c * GAM_RC_WIN + f) * 3 + 0];
+        const int ix = __float_as_int(apart[(c * GAM_RC_WIN + f) * 3 + 1]);
+        if (m > M || (m == M && ix < bi)) { M = m; bi = ix; }
+      }
+      float S = 0.f;
+      if (a.dump != nullptr)
+        for (int c = 0; c < C; ++c) {
+          const float m = apart[(c * GAM_RC_WIN + f) * 3 + 0];
+          if (m > -INFINITY) S += apart[(c * GAM_RC_WIN + f) * 3 + 2] * expf(m - M);
+        }
+      lab_s[f] = bi;
+      lse_s[f] = M + logf(S);
+    }
+    __syncthreads();
+    // first non-blank frame of the window (uniform scan, W <= 16)
+    int fstar = W;
+    for (int f = 0; f < W; ++f)
+      if (lab_s[f] != blank) { fstar = f; break; }
+    const int n_eval = fstar < W ? fstar + 1 : W;   // joint evaluations the sequential loop performs
+    if (a.dump != nullptr) {
+      for (int f = 0; f < n_eval; ++f) {
+        if (n_dump + f < a.dump_cap) {
+          float* dp = a.dump + ((size_t)b * a.dump_cap + n_dump + f) * V;
+          const float lse = lse_s[f];
+          for (int vl = tid; v0 + vl < v1; vl += 256) dp[v0 + vl] = lgw[f * LLD + vl] - lse;
+        }
+      }
+    }
+    n_dump += n_eval;
+    if (fstar == W) {            // W blank frames
+      t += W;
+      sym = 0;
+    } else {                     // emission at frame t + fstar (decoding.py:175-178)
+      const int k = lab_s[fstar];
+      const int te = t + fstar;
+      if (fstar > 0) sym = 0;
+      if (cm == 0 && tid == 0 && n_out < a.cap) {
+        a.ids[(size_t)b * a.cap + n_out] = k;
+        a.frames[(size_t)b * a.cap + n_out] = te;
+      }
+      ++n_out;
+      ++sym;
+      label = k;
+      for (int i = tid; i < H; i += 256) h_s[i] = hn_s[i];
+      for (int ii = tid; i0 + ii < i1; ii += 256) c_s[ii] = cn_s[ii];
+      need_pred = true;
+      if (sym >= a.max_symbols) { t = te + 1; sym = 0; }   // frame advances regardless (decoding.py:189-205)
+      else t = te;
+    }
+    __syncthreads();
+  }
+  if (cm == 0 && tid == 0) {
+    a.counts[b] = dead ? -1 : (n_out < a.cap ? n_out : a.cap);
+    if (a.dump_count != nullptr) a.dump_count[b] = n_dump;
+  }
+}

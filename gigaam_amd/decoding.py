@@ -41,6 +41,10 @@ class Tokenizer:
 
 def _ragged(ids: Tensor, frames: Tensor, counts: Tensor) -> List[Tuple[List[int], List[int]]]:
     n = counts.cpu().tolist()
+    if n and min(n) < 0:   # gam_decode_cluster.h: a hand-off inside a decode cluster timed out (counts[b] = -1)
+        from ._lib import GigaAMHipError
+        raise GigaAMHipError("RNN-T cluster decode: a workgroup hand-off timed out (GPU shared with another job?); "
+                             "set GAM_RNNT_CLUSTER=0 to decode with one workgroup per utterance")
     width = max(n) if n else 0
     ids_h = ids[:, :width].cpu()
     fr_h = frames[:, :width].cpu()

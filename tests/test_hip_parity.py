@@ -439,3 +439,28 @@ def test_batching_edge_cases_v3(revision):
     wlen = torch.tensor([3200, 5000])
     enc, elen = eng.encode(*eng.frontend(wav, wlen))
     assert enc.shape[0] == 2 and bool(torch.isfinite(enc).all()) and elen.cpu().tolist() == [5, 8]
+
+
+@pytest.mark.parametrize("cluster", ["0", "1", "2", "3", "5", "8"])
+@pytest.mark.parametrize("case", ["v2_rnnt_l2", "v3_e2e_rnnt_l2_dense"])
+def test_rnnt_cluster_sizes(case, cluster, monkeypatch):
+    """The RNN-T decode with C workgroups per utterance (gam_decode_cluster.h) for every way of slicing the hidden
+    units / joint rows / classes over the cluster, and the one-workgroup kernel (C = 0): ids, frames, number of joint
+    evaluations and every log-prob against the reference's, exactly as in test_rnnt_ids_frames_and_logits."""
+    monkeypatch.setenv("GAM_RNNT_CLUSTER", cluster)
+    ck, wav, wlen, gold = load_case(case)
+    eng = _engine(ck)
+    ms = ck["cfg"]["decoding"]["max_symbols_per_step"]
+    ref = split_ragged(gold["ids"], gold["frames"], gold["counts"].tolist())
+    want = golden_trace(gold)
+    enc_ref, elen_ref = torch.from_numpy(gold["encoded"]), torch.from_numpy(gold["enc_len"])
+    ids, frames, counts, dump, dcount = eng.rnnt_greedy(enc_ref, elen_ref, ms, dump_cap=max(w.shape[0] for w in want))
+    assert ragged_from_device(ids, frames, counts) == ref
+    assert dcount.cpu().tolist() == [w.shape[0] for w in want]
+    for i, w in enumerate(want):
+        err = float((dump[i, : w.shape[0]].cpu() - w).abs().max())
+        assert err < TOL_LOGP, (case, cluster, i, err)
+    # reruns are bit-identical (the hand-off carries no race)
+    for _ in range(3):
+        again = eng.rnnt_greedy(enc_ref, elen_ref, ms)
+        assert ragged_from_device(*again) == ref
