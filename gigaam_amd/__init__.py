@@ -55,7 +55,8 @@ def _normalize_device(device: Optional[Union[str, torch.device]]) -> torch.devic
     return torch.device(device) if isinstance(device, str) else device
 
 
-def model_from_checkpoint(checkpoint: dict, device: Optional[Union[str, torch.device]] = None) -> Union[GigaAM, GigaAMASR, GigaAMEmo]:
+def model_from_checkpoint(checkpoint: dict, device: Optional[Union[str, torch.device]] = None,
+                          fp16_encoder: bool = False) -> Union[GigaAM, GigaAMASR, GigaAMEmo]:
     """Build a model from an in-memory ``{"cfg", "state_dict"}`` checkpoint (the layout
     of the reference's .ckpt files, gigaam/__init__.py:167-185)."""
     cfg = checkpoint["cfg"]
@@ -68,7 +69,10 @@ def model_from_checkpoint(checkpoint: dict, device: Optional[Union[str, torch.de
         model = GigaAMASR(cfg)
     model.load_state_dict(checkpoint["state_dict"])
     model = model.eval()
-    return model.to(_normalize_device(device))
+    dev = _normalize_device(device)
+    if fp16_encoder and dev.type != "cpu":   # gigaam/__init__.py:188-189
+        model.encoder = model.encoder.half()
+    return model.to(dev)
 
 
 def load_model(model_name: str, fp16_encoder: bool = True, use_flash: Optional[bool] = False,
@@ -79,21 +83,25 @@ def load_model(model_name: str, fp16_encoder: bool = True, use_flash: Optional[b
     ``model_name`` is a model name (checkpoint expected at
     ``<download_root>/<name>.ckpt``; this build has no network access, so a missing
     file raises instead of downloading) or a path to a ``.ckpt`` holding
-    ``{"cfg", "state_dict"}``.  ``fp16_encoder`` / ``use_flash`` select torch code
-    paths in the reference; the HIP path always computes in fp32 with its own
-    attention kernel, so they are accepted and ignored."""
-    del fp16_encoder, use_flash
+    ``{"cfg", "state_dict"}``.  ``fp16_encoder`` (default True, as in the reference) on a GPU
+    gives the reference's storage contract -- ``_dtype`` float16, the waveform cast to float16 by
+    ``prepare_wav``, ``encoded`` returned as float16 -- with fp32 arithmetic inside (the reference
+    computes under fp16 autocast there); pass ``fp16_encoder=False`` for the fp32 contract of the
+    reference's CPU path.  ``use_flash`` selects torch code paths in the reference; the HIP attention
+    kernel is the only path here, so it is accepted and ignored."""
+    del use_flash
     device_obj = _normalize_device(device)
     download_root = download_root or _CACHE_DIR
     local = os.path.expanduser(model_name)
     if os.path.isfile(local):
         ckpt = torch.load(local, map_location="cpu", weights_only=False)
         if "cfg" not in ckpt:  # fine-tuned Lightning checkpoint (gigaam/__init__.py:139-156)
-            base = load_model(ckpt["hyper_parameters"]["model_name"], device=device_obj, download_root=download_root)
+            base = load_model(ckpt["hyper_parameters"]["model_name"], fp16_encoder=fp16_encoder, device=device_obj,
+                              download_root=download_root)
             sd = {k: v for k, v in ckpt["state_dict"].items() if k.startswith(("preprocessor.", "encoder.", "head."))}
             base.load_state_dict(sd)
             return base
-        return model_from_checkpoint(ckpt, device_obj)
+        return model_from_checkpoint(ckpt, device_obj, fp16_encoder)
     names = _SHORT_NAMES + list(_MODEL_HASHES.keys())
     if model_name not in names:
         raise ValueError(f"Model '{model_name}' not found. Available model names: {names}")
@@ -110,4 +118,4 @@ def load_model(model_name: str, fp16_encoder: bool = True, use_flash: Optional[b
     if (model_name == "v1_rnnt" or "e2e" in model_name) and os.path.exists(tok):
         ckpt["cfg"].decoding.model_path = tok
     ckpt["cfg"].model_name = model_name
-    return model_from_checkpoint(ckpt, device_obj)
+    return model_from_checkpoint(ckpt, device_obj, fp16_encoder)

@@ -94,6 +94,17 @@ __device__ __forceinline__ void gam_store4(float* base, size_t row_off, int c, f
     *reinterpret_cast<gam_half4*>(p + 32) = lo;
   }
 }
+__device__ __forceinline__ void gam_store2(float* base, size_t row_off, int c, float x0, float x1, int split) {   // c % 2 == 0
+  if (!split) {
+    *reinterpret_cast<float2*>(base + row_off + c) = make_float2(x0, x1);
+  } else {
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    _Float16* p = reinterpret_cast<_Float16*>(base) + row_off * 2 + (c >> 5) * 64 + (c & 31);
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    *reinterpret_cast<half2_t*>(p) = (half2_t){h0, h1};
+    *reinterpret_cast<half2_t*>(p + 32) = (half2_t){(_Float16)(x0 - (float)h0), (_Float16)(x1 - (float)h1)};
+  }
+}
 __device__ __forceinline__ void gam_store1(float* base, size_t row_off, int c, float x, int split) {
   if (!split) {
     base[row_off + c] = x;

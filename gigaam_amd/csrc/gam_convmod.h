@@ -8,6 +8,7 @@
 // N = 16 032, d = 768).
 #pragma once
 #include "gam_common.h"
+#include <type_traits>
 
 struct GamConvModArgs {
   const float* u;      // [B*Ta, 2d]  pointwise_conv1 output (bias included)
@@ -32,7 +33,7 @@ struct GamConvModArgs {
 // once per tap.  Per output the fmaf chain runs k = 0 .. KS-1 as before: bit-identical results.
 template <int KS>
 __global__ __launch_bounds__(256, 2) void gam_convmod_bn_kernel(GamConvModArgs a) {
-  constexpr int TT = 128, PAD = (KS - 1) / 2, ROWS = TT + KS - 1, OUT = TT / 16;
+  constexpr int TT = 128, PAD = (KS - 1) / 2, ROWS = (TT + KS - 1 + 15) / 16 * 16, OUT = TT / 16;
   __shared__ f32x4 tile[ROWS * 16];   // [row][quad]: 256-byte rows; a 16-lane ds_read_b128 group covers one row
   __shared__ f32x4 wl[KS * 16];       // [k][quad]
   const int tid = threadIdx.x;
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void gam_convmod_bn_kernel(GamConvModArgs a
   const size_t rowbase = (size_t)b * a.Ta;
   // GLU'd input tile: row r of the tile is loaded by row group r % 16 (clamped row, value masked afterwards --
   // a per-element "if in range: load" keeps one load outstanding per thread)
-  constexpr int NLD = (ROWS + 15) / 16;
+  constexpr int NLD = ROWS / 16;      // (ROWS is rounded up to whole row groups: no "row in range" branch anywhere)
   f32x4 ua[NLD], ub[NLD];
 #pragma unroll
   for (int u = 0; u < NLD; ++u) {
@@ -65,43 +66,56 @@ __global__ __launch_bounds__(256, 2) void gam_convmod_bn_kernel(GamConvModArgs a
   for (int u = 0; u < NLD; ++u) {
     const int rr = rg + 16 * u;
     const int t = t0 - PAD + rr;
-    if (rr < ROWS) {
-      f32x4 g = {0.f, 0.f, 0.f, 0.f};
-      if (t >= 0 && t < klen)
-        g = (f32x4){ua[u].x * gam_sigmoid(ub[u].x), ua[u].y * gam_sigmoid(ub[u].y), ua[u].z * gam_sigmoid(ub[u].z),
-                    ua[u].w * gam_sigmoid(ub[u].w)};
-      tile[rr * 16 + q] = g;
-    }
+    const float m = (t >= 0 && t < klen) ? 1.0f : 0.0f;   // a select, not a branch: padded frames enter the taps as 0
+    tile[rr * 16 + q] = (f32x4){m * ua[u].x * gam_sigmoid(ub[u].x), m * ua[u].y * gam_sigmoid(ub[u].y),
+                                m * ua[u].z * gam_sigmoid(ub[u].z), m * ua[u].w * gam_sigmoid(ub[u].w)};
   }
-  const f32x4 bias = *reinterpret_cast<const f32x4*>(a.dw_b + c);
-  const f32x4 sc = *reinterpret_cast<const f32x4*>(a.n_scale + c);
-  const f32x4 sh = *reinterpret_cast<const f32x4*>(a.n_shift + c);
   __syncthreads();
-  f32x4 win[OUT + KS - 1];
+  // The taps run over a register window of OUT + KS - 1 tile rows.  With all four channels of the lane in one
+  // window (38 x f32x4 + accumulators) hipcc spilled 36-62 VGPRs into the tap loop (112 us instead of 45), so the
+  // lane's channels go in two passes of a channel PAIR each (38 x 8-byte LDS reads, ~120 live VGPRs).
+  // The taps run over a register window of OUT + KS - 1 tile rows.  A window over all four channels of the lane
+  // (38 x f32x4 + accumulators) made hipcc spill 36-70 VGPRs into the tap loop (112 us instead of 45), and so did two
+  // unrolled channel-pair passes (it hoists both windows and all weight reads to the top).  So: a real, not
+  // unrolled, loop over the lane's two channel pairs -- 38 x 8-byte LDS reads and ~170 VGPRs per trip; each later
+  // weight read's address passes through an empty asm that consumes an accumulator of the tap before it, which
+  // pins it behind that tap (fetched two taps ahead).
+  int lofs = 0;   // always 0; laundered through the asm statements below
+#pragma unroll 1
+  for (int pc = 0; pc < 2; ++pc) {
+    const float2* tile2 = reinterpret_cast<const float2*>(tile) + pc;
+    const float2* wl2 = reinterpret_cast<const float2*>(wl) + pc + q * 2;
+    float2 win[OUT + KS - 1];
 #pragma unroll
-  for (int r = 0; r < OUT + KS - 1; ++r) win[r] = tile[(rg * OUT + r) * 16 + q];
-  f32x4 acc[OUT];
+    for (int r = 0; r < OUT + KS - 1; ++r) win[r] = tile2[((rg * OUT + r) * 16 + q) * 2];
+    float2 acc[OUT];
 #pragma unroll
-  for (int i = 0; i < OUT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < OUT; ++i) acc[i] = make_float2(0.f, 0.f);
+    float2 w_cur = wl2[lofs], w_nxt = wl2[lofs + 32];
 #pragma unroll
-  for (int k = 0; k < KS; ++k) {
-    const f32x4 w = wl[k * 16 + q];
+    for (int k = 0; k < KS; ++k) {
+      const float2 w = w_cur;
+      w_cur = w_nxt;
+#pragma unroll
+      for (int i = 0; i < OUT; ++i) {
+        acc[i].x = fmaf(w.x, win[i + k].x, acc[i].x);
+        acc[i].y = fmaf(w.y, win[i + k].y, acc[i].y);
+      }
+      asm volatile("" : "+v"(lofs), "+v"(acc[0].x));
+      if (k + 2 < KS) w_nxt = wl2[lofs + (k + 2) * 32];
+    }
+    const int cc = c + 2 * pc;
+    const float2 bias = *reinterpret_cast<const float2*>(a.dw_b + cc);
+    const float2 sc = *reinterpret_cast<const float2*>(a.n_scale + cc);
+    const float2 sh = *reinterpret_cast<const float2*>(a.n_shift + cc);
 #pragma unroll
     for (int i = 0; i < OUT; ++i) {
-      acc[i].x = fmaf(w.x, win[i + k].x, acc[i].x);
-      acc[i].y = fmaf(w.y, win[i + k].y, acc[i].y);
-      acc[i].z = fmaf(w.z, win[i + k].z, acc[i].z);
-      acc[i].w = fmaf(w.w, win[i + k].w, acc[i].w);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < OUT; ++i) {
-    const int t = t0 + rg * OUT + i;
-    const f32x4 y = (acc[i] + bias) * sc + sh;
-    const float o0 = gam_silu(y.x), o1 = gam_silu(y.y), o2 = gam_silu(y.z), o3 = gam_silu(y.w);
-    if (t < a.Ta) {
-      if (a.z_split) gam_range_note(a.range_flag, o0, o1, o2, o3);
-      gam_store4(a.z, (rowbase + t) * (size_t)a.d, c, o0, o1, o2, o3, a.z_split);
+      const int t = t0 + rg * OUT + i;
+      const float v0 = gam_silu((acc[i].x + bias.x) * sc.x + sh.x), v1 = gam_silu((acc[i].y + bias.y) * sc.y + sh.y);
+      if (t < a.Ta) {
+        if (a.z_split) gam_range_note(a.range_flag, v0, v1, 0.f, 0.f);
+        gam_store2(a.z, (rowbase + t) * (size_t)a.d, cc, v0, v1, a.z_split);
+      }
     }
   }
 }

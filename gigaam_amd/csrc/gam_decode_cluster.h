@@ -141,7 +141,9 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
         float acc[NR];
 #pragma unroll
         for (int j = 0; j < NR; ++j) acc[j] = a.gate_tab[(size_t)label * 4 * H + grow[j]];
-        constexpr int KU = NR == 1 ? 16 : (NR == 2 ? 8 : 4);   // float4 loads in flight per row slot
+        // float4 loads in flight per row slot: the step is L2-LATENCY bound (each batch of loads is one round trip),
+        // so as many as the registers hold -- ~160 VGPRs of weights per thread
+        constexpr int KU = NR == 1 ? 40 : (NR == 2 ? 20 : (NR == 3 ? 12 : (NR == 5 ? 8 : 4)));
         for (int q0 = 0; q0 < HQ; q0 += KU) {
           f32x4 w[KU][NR];
 #pragma unroll
@@ -195,12 +197,12 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
           for (int rr = tid; r0 + rr < r1; rr += 256) {
             const int r = r0 + rr;
             float acc = a.bpred[r];
-            for (int q0 = 0; q0 < HQ; q0 += 8) {
-              f32x4 w[8];
+            for (int q0 = 0; q0 < HQ; q0 += 16) {
+              f32x4 w[16];
 #pragma unroll
-              for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const f32x4*>(g.wpred_q + ((size_t)(q0 + u < HQ ? q0 + u : HQ - 1) * JH + r) * 4);
+              for (int u = 0; u < 16; ++u) w[u] = *reinterpret_cast<const f32x4*>(g.wpred_q + ((size_t)(q0 + u < HQ ? q0 + u : HQ - 1) * JH + r) * 4);
 #pragma unroll
-              for (int u = 0; u < 8; ++u)
+              for (int u = 0; u < 16; ++u)
                 if (q0 + u < HQ) {
                   const f32x4 hv = *reinterpret_cast<const f32x4*>(hn_s + 4 * (q0 + u));
                   acc = fmaf(w[u].x, hv.x, acc); acc = fmaf(w[u].y, hv.y, acc); acc = fmaf(w[u].z, hv.z, acc); acc = fmaf(w[u].w, hv.w, acc);
@@ -214,12 +216,12 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
             const int r = r0 + rr;
             const int qa = part * HQ / P, qb = (part + 1) * HQ / P;
             float acc = part == 0 ? a.bpred[r] : 0.f;
-            for (int q0 = qa; q0 < qb; q0 += 8) {
-              f32x4 w[8];
+            for (int q0 = qa; q0 < qb; q0 += 16) {
+              f32x4 w[16];
 #pragma unroll
-              for (int u = 0; u < 8; ++u) w[u] = *reinterpret_cast<const f32x4*>(g.wpred_q + ((size_t)(q0 + u < qb ? q0 + u : qb - 1) * JH + r) * 4);
+              for (int u = 0; u < 16; ++u) w[u] = *reinterpret_cast<const f32x4*>(g.wpred_q + ((size_t)(q0 + u < qb ? q0 + u : qb - 1) * JH + r) * 4);
 #pragma unroll
-              for (int u = 0; u < 8; ++u)
+              for (int u = 0; u < 16; ++u)
                 if (q0 + u < qb) {
                   const f32x4 hv = *reinterpret_cast<const f32x4*>(hn_s + 4 * (q0 + u));
                   acc = fmaf(w[u].x, hv.x, acc); acc = fmaf(w[u].y, hv.y, acc); acc = fmaf(w[u].z, hv.z, acc); acc = fmaf(w[u].w, hv.w, acc);
@@ -281,7 +283,20 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       const float* wr = (wout_l != nullptr ? wout_l + (size_t)(vc - v0) * WLD : a.wout + (size_t)vc * JH) + 4 * lg4;
       const float* zr = zw + li * ZLD + 4 * lg4;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int k0 = 0; k0 + 64 <= JH; k0 += 64) {
+      for (int k0 = 0; k0 + 128 <= JH; k0 += 128) {   // 8 x 16-byte loads in flight per lane (L2-streamed slice: one round trip per 128 k)
+        float4 wf[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wf[u] = *reinterpret_cast<const float4*>(wr + k0 + 16 * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const float4 zf = *reinterpret_cast<const float4*>(zr + k0 + 16 * u);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.x, wf[u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf[u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf[u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf[u].w, acc, 0, 0, 0);
+        }
+      }
+      for (int k0 = JH / 128 * 128; k0 + 64 <= JH; k0 += 64) {
         float4 wf[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const float4*>(wr + k0 + 16 * u);

@@ -106,6 +106,13 @@ __device__ __forceinline__ void gam_gemm_epilogue(const GamGemmArgs& g, const f3
   }
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
+    float rsv[16];   // row factors of this 32-row slab, loaded together (see gam_gemm_sp.h)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
+      row = row < g.M ? row : g.M - 1;
+      rsv[r] = g.a_rs != nullptr ? g.a_rs[row] : 1.0f;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
@@ -120,7 +127,7 @@ __device__ __forceinline__ void gam_gemm_epilogue(const GamGemmArgs& g, const f3
           orow = (long)bb * g.out_rpb + tt + g.out_shift;
         }
       }
-      const float rowscale = accscale * (g.a_rs != nullptr ? g.a_rs[row] : 1.0f);
+      const float rowscale = accscale * rsv[r];
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
         const int col = n0 + wn * 64 + tn * 32 + lcol;

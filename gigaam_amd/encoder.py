@@ -66,7 +66,10 @@ class ConformerEncoder(_EngineModule):
         return None, self.cfg, None
 
     def forward(self, audio_signal: Tensor, length: Tensor) -> Tuple[Tensor, Tensor]:
-        return self.engine.encode(audio_signal, length)
+        enc, elen = self.engine.encode(audio_signal, length)
+        if self._anchor.dtype != torch.float32:   # .half()-ed encoder (fp16_encoder=True): fp16 at the boundary
+            enc = enc.to(self._anchor.dtype)
+        return enc, elen
 
     def forward_layers(self, audio_signal: Tensor, length: Tensor, n_layers: int) -> Tuple[Tensor, Tensor]:
         """Test hook: token-major activations [B,T',d_model] after ``n_layers`` layers."""

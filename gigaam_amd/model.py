@@ -113,7 +113,8 @@ class GigaAM(nn.Module):
 
     @property
     def _dtype(self) -> torch.dtype:
-        return next(self.parameters()).dtype
+        # the reference's first parameter is the encoder's (its FeatureExtractor holds buffers only): model.py:43-45
+        return next(self.encoder.parameters()).dtype
 
     def prepare_wav(self, wav_file: str) -> Tuple[Tensor, Tensor]:
         wav = load_audio(wav_file)

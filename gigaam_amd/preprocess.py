@@ -79,8 +79,11 @@ class _EngineModule(nn.Module):
             self._engine = HipEngine(build_config(pre, enc, head), self._pending, self._anchor.device)
         return self._engine
 
-    def half(self):  # fp16_encoder (reference gigaam/__init__.py:188-189): the HIP path computes fp32
-        return self
+    def half(self):
+        """``model.encoder.half()`` (reference gigaam/__init__.py:188-189, fp16_encoder=True on a GPU): the storage
+        contract follows -- ``_dtype`` becomes float16 (the anchor parameter is converted like any other), inputs
+        arrive as float16 and ``encoded`` leaves as float16 -- while the kernels keep computing in fp32."""
+        return super().half()
 
 
 class FeatureExtractor(_EngineModule):

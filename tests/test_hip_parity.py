@@ -261,7 +261,7 @@ def test_model_api_transcribe(tmp_path):
     ck = synth.make_checkpoint("v2_ctc", seed=1, n_layers=2)
     path = str(tmp_path / "model.ckpt")
     torch.save(ck, path)
-    model = gigaam_amd.load_model(path, device="cuda:0")
+    model = gigaam_amd.load_model(path, fp16_encoder=False, device="cuda:0")   # the fp32 contract of the reference's CPU path
     wav, wlen = synth.synth_audio(1, 5.0, seed=0)
     pcm = (wav[0].numpy() * 32768.0).round().clip(-32768, 32767).astype(np.int16)
     wpath = str(tmp_path / "clip.wav")
@@ -307,7 +307,7 @@ def test_model_api_emotion(tmp_path):
     ck = synth.make_checkpoint("emo", seed=1, n_layers=2)
     path = str(tmp_path / "emo.ckpt")
     torch.save(ck, path)
-    model = gigaam_amd.load_model(path, device="cuda:0")
+    model = gigaam_amd.load_model(path, fp16_encoder=False, device="cuda:0")
     assert isinstance(model, gigaam_amd.GigaAMEmo)
     wav, _ = synth.synth_audio(1, 3.0, seed=5)
     pcm = (wav[0].numpy() * 32768.0).round().clip(-32768, 32767).astype(np.int16)
@@ -464,3 +464,30 @@ def test_rnnt_cluster_sizes(case, cluster, monkeypatch):
     for _ in range(3):
         again = eng.rnnt_greedy(enc_ref, elen_ref, ms)
         assert ragged_from_device(*again) == ref
+
+
+def test_fp16_encoder_contract(tmp_path):
+    """load_model(fp16_encoder=True) on a GPU (the reference's default, gigaam/__init__.py:188-189; model.py:39-55):
+    ``_dtype`` is float16, prepare_wav hands the model a float16 waveform, embed_audio returns float16 -- here with
+    fp32 arithmetic inside, so the result equals the fp32 path on the same (fp16-rounded) waveform, rounded once."""
+    import wave
+    import gigaam_amd
+    from gigaam_amd import synth
+    ck = synth.make_checkpoint("v2_ctc", seed=1, n_layers=2)
+    path = str(tmp_path / "model.ckpt")
+    torch.save(ck, path)
+    m16 = gigaam_amd.load_model(path, device="cuda:0")                       # fp16_encoder defaults to True
+    m32 = gigaam_amd.load_model(path, fp16_encoder=False, device="cuda:0")
+    assert m16._dtype == torch.float16 and m32._dtype == torch.float32 and m16._device.type == "cuda"
+    wav, _ = synth.synth_audio(1, 3.0, seed=4)
+    pcm = (wav[0].numpy() * 32768.0).round().clip(-32768, 32767).astype(np.int16)
+    wpath = str(tmp_path / "clip.wav")
+    with wave.open(wpath, "wb") as wf:
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000); wf.writeframes(pcm.tobytes())
+    w16, l16 = m16.prepare_wav(wpath)
+    assert w16.dtype == torch.float16
+    e16, n16 = m16.embed_audio(wpath)
+    assert e16.dtype == torch.float16 and n16.dtype == torch.int32
+    e32, n32 = m32.forward(w16.float(), l16)      # the same fp16-rounded samples through the fp32 contract
+    assert torch.equal(n16, n32) and torch.equal(e16, e32.half())
+    assert isinstance(str(m16.transcribe(wpath)), str)
