@@ -1154,7 +1154,7 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
   // (8 utterance columns, one per XCD; C members of a cluster share an XCD.)
   {
     const int nu8 = gam_cdiv(B, 8);
-    int C = 256 / (8 * nu8);
+    int C = (256 - 16) / (8 * nu8);   // one workgroup per CU with a few CUs to spare (members spin on each other)
     C = C > 8 ? 8 : C;
     if (h->rnnt_cluster >= 0) C = h->rnnt_cluster < C ? h->rnnt_cluster : C;
     if (C >= 1 && JH % 4 == 0 && a.H % 4 == 0) {
@@ -1178,6 +1178,13 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
     HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<NRV>), 160 * 1024, AT));               \
     hipLaunchKernelGGL(gam_rnnt_cluster_kernel<NRV>, grid, dim3(256), sm, s, ca);                                          \
   }
+        static std::atomic<unsigned long long> at1r{0};
+        if (nr == 1 && a.H == 320) {   // W_hh rows register-resident (gam_decode_cluster.h RESQ)
+          HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<1, 80>), 160 * 1024, at1r));
+          hipLaunchKernelGGL((gam_rnnt_cluster_kernel<1, 80>), grid, dim3(256), sm, s, ca);
+          HIPCHK(h, hipGetLastError());
+          return 0;
+        }
         switch (nr) {
           case 1: GAM_RC_LAUNCH(1, at1); break;
           case 2: GAM_RC_LAUNCH(2, at2); break;

@@ -32,8 +32,11 @@ struct GamConvModArgs {
 // (8 outputs read 8 + KS - 1 tile rows once); the KS x 64 weights sit in LDS as [k][channel] and are read
 // once per tap.  Per output the fmaf chain runs k = 0 .. KS-1 as before: bit-identical results.
 template <int KS>
-__global__ __launch_bounds__(256, 2) void gam_convmod_bn_kernel(GamConvModArgs a) {
-  constexpr int TT = 128, PAD = (KS - 1) / 2, ROWS = (TT + KS - 1 + 15) / 16 * 16, OUT = TT / 16;
+__global__ __launch_bounds__(512, 4) void gam_convmod_bn_kernel(GamConvModArgs a) {
+  // 512 threads = 16 channel quads x 32 row groups, 4 outputs per thread: the register window stays at ~70 VGPRs, so
+  // two workgroups (16 waves) share a CU -- with 8 outputs per thread (193 VGPRs, 8 waves per CU) the kernel ran
+  // no faster than the 4-byte-load version it replaced (49 vs 45 us): too few waves to cover the load phase.
+  constexpr int NRG = 32, TT = 128, PAD = (KS - 1) / 2, ROWS = (TT + KS - 1 + NRG - 1) / NRG * NRG, OUT = TT / NRG;
   __shared__ f32x4 tile[ROWS * 16];   // [row][quad]: 256-byte rows; a 16-lane ds_read_b128 group covers one row
   __shared__ f32x4 wl[KS * 16];       // [k][quad]
   const int tid = threadIdx.x;
@@ -44,27 +47,27 @@ __global__ __launch_bounds__(256, 2) void gam_convmod_bn_kernel(GamConvModArgs a
   const size_t rowbase = (size_t)b * a.Ta;
   // GLU'd input tile: row r of the tile is loaded by row group r % 16 (clamped row, value masked afterwards --
   // a per-element "if in range: load" keeps one load outstanding per thread)
-  constexpr int NLD = ROWS / 16;      // (ROWS is rounded up to whole row groups: no "row in range" branch anywhere)
+  constexpr int NLD = ROWS / NRG;     // (ROWS is rounded up to whole row groups: no "row in range" branch anywhere)
   f32x4 ua[NLD], ub[NLD];
 #pragma unroll
   for (int u = 0; u < NLD; ++u) {
-    const int t = t0 - PAD + rg + 16 * u;
+    const int t = t0 - PAD + rg + NRG * u;
     const int tc = t < 0 ? 0 : (t < a.Ta ? t : a.Ta - 1);
     const float* up = a.u + (rowbase + tc) * (size_t)(2 * a.d);
     ua[u] = *reinterpret_cast<const f32x4*>(up + c);
     ub[u] = *reinterpret_cast<const f32x4*>(up + a.d + c);
   }
-  {   // weights [d][KS] -> wl[k][quad]: this thread stages taps k = rg + 16 i of its 4 channels
+  {   // weights [d][KS] -> wl[k][quad]: this thread stages taps k = rg + NRG i of its 4 channels
 #pragma unroll
-    for (int i = 0; i < (KS + 15) / 16; ++i) {
-      const int k = rg + 16 * i;
+    for (int i = 0; i < (KS + NRG - 1) / NRG; ++i) {
+      const int k = rg + NRG * i;
       if (k < KS) wl[k * 16 + q] = (f32x4){a.dw_w[(size_t)c * KS + k], a.dw_w[(size_t)(c + 1) * KS + k],
                                            a.dw_w[(size_t)(c + 2) * KS + k], a.dw_w[(size_t)(c + 3) * KS + k]};
     }
   }
 #pragma unroll
   for (int u = 0; u < NLD; ++u) {
-    const int rr = rg + 16 * u;
+    const int rr = rg + NRG * u;
     const int t = t0 - PAD + rr;
     const float m = (t >= 0 && t < klen) ? 1.0f : 0.0f;   // a select, not a branch: padded frames enter the taps as 0
     tile[rr * 16 + q] = (f32x4){m * ua[u].x * gam_sigmoid(ub[u].x), m * ua[u].y * gam_sigmoid(ub[u].y),
@@ -74,48 +77,51 @@ __global__ __launch_bounds__(256, 2) void gam_convmod_bn_kernel(GamConvModArgs a
   // The taps run over a register window of OUT + KS - 1 tile rows.  With all four channels of the lane in one
   // window (38 x f32x4 + accumulators) hipcc spilled 36-62 VGPRs into the tap loop (112 us instead of 45), so the
   // lane's channels go in two passes of a channel PAIR each (38 x 8-byte LDS reads, ~120 live VGPRs).
-  // The taps run over a register window of OUT + KS - 1 tile rows.  A window over all four channels of the lane
-  // (38 x f32x4 + accumulators) made hipcc spill 36-70 VGPRs into the tap loop (112 us instead of 45), and so did two
-  // unrolled channel-pair passes (it hoists both windows and all weight reads to the top).  So: a real, not
-  // unrolled, loop over the lane's two channel pairs -- 38 x 8-byte LDS reads and ~170 VGPRs per trip; each later
-  // weight read's address passes through an empty asm that consumes an accumulator of the tap before it, which
-  // pins it behind that tap (fetched two taps ahead).
+  // Taps: output i needs tile rows i .. i + KS - 1.  Holding that whole window in registers (38 x f32x4) made hipcc
+  // spill 36-70 VGPRs into the tap loop, and it hoists every loop-invariant LDS read to the top whatever the source
+  // order.  So the window ROLLS: tap k uses rows k .. k+OUT-1, row k+OUT+1 and the weights of tap k+2 are fetched
+  // during tap k, and each of those reads takes its address through an empty asm that also consumes an accumulator of
+  // tap k -- ALL of them: pinning one component made hipcc run that component's whole chain first and spill 222
+  // VGPRs -- so it cannot be issued earlier.  ~6 rows live at a time: the kernel fits 128 VGPRs, 16 waves per CU.
+  const f32x4* trow = tile + (rg * OUT) * 16 + q;
+  const f32x4* wq = wl + q;
   int lofs = 0;   // always 0; laundered through the asm statements below
-#pragma unroll 1
-  for (int pc = 0; pc < 2; ++pc) {
-    const float2* tile2 = reinterpret_cast<const float2*>(tile) + pc;
-    const float2* wl2 = reinterpret_cast<const float2*>(wl) + pc + q * 2;
-    float2 win[OUT + KS - 1];
+  f32x4 win[OUT + KS - 1];
 #pragma unroll
-    for (int r = 0; r < OUT + KS - 1; ++r) win[r] = tile2[((rg * OUT + r) * 16 + q) * 2];
-    float2 acc[OUT];
+  for (int r = 0; r < OUT + 1; ++r) win[r] = trow[r * 16];
+  f32x4 acc[OUT];
 #pragma unroll
-    for (int i = 0; i < OUT; ++i) acc[i] = make_float2(0.f, 0.f);
-    float2 w_cur = wl2[lofs], w_nxt = wl2[lofs + 32];
+  for (int i = 0; i < OUT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 w_cur = wq[0], w_nxt = wq[16];
 #pragma unroll
-    for (int k = 0; k < KS; ++k) {
-      const float2 w = w_cur;
-      w_cur = w_nxt;
-#pragma unroll
-      for (int i = 0; i < OUT; ++i) {
-        acc[i].x = fmaf(w.x, win[i + k].x, acc[i].x);
-        acc[i].y = fmaf(w.y, win[i + k].y, acc[i].y);
-      }
-      asm volatile("" : "+v"(lofs), "+v"(acc[0].x));
-      if (k + 2 < KS) w_nxt = wl2[lofs + (k + 2) * 32];
-    }
-    const int cc = c + 2 * pc;
-    const float2 bias = *reinterpret_cast<const float2*>(a.dw_b + cc);
-    const float2 sc = *reinterpret_cast<const float2*>(a.n_scale + cc);
-    const float2 sh = *reinterpret_cast<const float2*>(a.n_shift + cc);
+  for (int k = 0; k < KS; ++k) {
+    const f32x4 w = w_cur;
+    w_cur = w_nxt;
 #pragma unroll
     for (int i = 0; i < OUT; ++i) {
-      const int t = t0 + rg * OUT + i;
-      const float v0 = gam_silu((acc[i].x + bias.x) * sc.x + sh.x), v1 = gam_silu((acc[i].y + bias.y) * sc.y + sh.y);
-      if (t < a.Ta) {
-        if (a.z_split) gam_range_note(a.range_flag, v0, v1, 0.f, 0.f);
-        gam_store2(a.z, (rowbase + t) * (size_t)a.d, cc, v0, v1, a.z_split);
-      }
+      acc[i].x = fmaf(w.x, win[i + k].x, acc[i].x);
+      acc[i].y = fmaf(w.y, win[i + k].y, acc[i].y);
+      acc[i].z = fmaf(w.z, win[i + k].z, acc[i].z);
+      acc[i].w = fmaf(w.w, win[i + k].w, acc[i].w);
+    }
+    static_assert(OUT == 4, "the pin below names the 16 accumulator components of a tap");
+    asm volatile("" : "+v"(lofs), "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[0].z), "+v"(acc[0].w), "+v"(acc[1].x), "+v"(acc[1].y),
+                 "+v"(acc[1].z), "+v"(acc[1].w), "+v"(acc[2].x), "+v"(acc[2].y), "+v"(acc[2].z), "+v"(acc[2].w), "+v"(acc[3].x),
+                 "+v"(acc[3].y), "+v"(acc[3].z), "+v"(acc[3].w));
+    if (k + 2 < KS) w_nxt = wq[(k + 2) * 16 + lofs];
+    if (k + OUT + 1 < OUT + KS - 1) win[k + OUT + 1] = trow[(k + OUT + 1) * 16 + lofs];
+  }
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(a.dw_b + c);
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(a.n_scale + c);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(a.n_shift + c);
+#pragma unroll
+  for (int i = 0; i < OUT; ++i) {
+    const int t = t0 + rg * OUT + i;
+    const f32x4 y = (acc[i] + bias) * sc + sh;
+    const float v0 = gam_silu(y.x), v1 = gam_silu(y.y), v2 = gam_silu(y.z), v3 = gam_silu(y.w);
+    if (t < a.Ta) {
+      if (a.z_split) gam_range_note(a.range_flag, v0, v1, v2, v3);
+      gam_store4(a.z, (rowbase + t) * (size_t)a.d, c, v0, v1, v2, v3, a.z_split);
     }
   }
 }
@@ -228,9 +234,9 @@ static inline hipError_t gam_launch_convmod(const GamConvModArgs& a, int layer_n
   if (!layer_norm) {
     if (a.d % 64 != 0) return hipErrorInvalidValue;
     dim3 grid(gam_cdiv(a.Ta, 128), a.d / 64, a.B);
-    if (a.ks == 31) hipLaunchKernelGGL(gam_convmod_bn_kernel<31>, grid, dim3(256), 0, s, a);
-    else if (a.ks == 5) hipLaunchKernelGGL(gam_convmod_bn_kernel<5>, grid, dim3(256), 0, s, a);
-    else if (a.ks == 9) hipLaunchKernelGGL(gam_convmod_bn_kernel<9>, grid, dim3(256), 0, s, a);
+    if (a.ks == 31) hipLaunchKernelGGL(gam_convmod_bn_kernel<31>, grid, dim3(512), 0, s, a);
+    else if (a.ks == 5) hipLaunchKernelGGL(gam_convmod_bn_kernel<5>, grid, dim3(512), 0, s, a);
+    else if (a.ks == 9) hipLaunchKernelGGL(gam_convmod_bn_kernel<9>, grid, dim3(512), 0, s, a);
     else return hipErrorInvalidValue;
   } else {
     if (a.d > 1024) return hipErrorInvalidValue;

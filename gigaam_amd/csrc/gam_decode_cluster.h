@@ -19,6 +19,9 @@
 //   * every spin is bounded (wall clock): a member that gives up sets the launch's status word, its cluster
 //     unwinds, and counts[b] = -1 tells the host (the Python shim raises) -- a workgroup that was not resident
 //     cannot hang the GPU.  The launcher sizes the grid to <= one workgroup per CU.
+// Tried and dropped (r02_s6): W_pred by COLUMN slices, each member publishing the partial product of its own h' slice so
+// that the h' gather and the pp reduction share one hand-off -- C x JH granules per step instead of JH made it slower
+// (config 3 decode 4.57 vs 4.13 ms).
 // Same arithmetic per (frame, state) as the single-workgroup kernel: gate sums run k = 0..H-1 in order, the
 // 16-frame joint window is the same v_mfma_f32_16x16x4_f32 product.
 #pragma once
@@ -66,9 +69,14 @@ static inline size_t gam_rnnt_cluster_smem(int H, int JH, int V, int C, int nr, 
   if (wout_slice_in_lds) f += (size_t)nV * (JH + 4);
   return sizeof(float) * f;
 }
-__host__ __device__ static inline size_t gam_rnnt_cluster_xgranules(int H, int JH, int C) { return 2 * ((size_t)H + JH + (size_t)C * 48); }
+__host__ __device__ static inline size_t gam_rnnt_cluster_xgranules(int H, int JH, int C) {
+  return 2 * ((size_t)H + (size_t)JH + (size_t)C * 48);
+}
 
-template <int NR>   // gate-row slots per thread: 4 * ceil(H / C) <= 256 * NR
+// NR: gate-row slots per thread, 4 * ceil(H / C) <= 256 * NR.  RESQ > 0 (only with NR == 1): H == 4 * RESQ and the
+// thread keeps its gate row of W_hh (RESQ x 16 bytes) in registers for the whole decode -- at C >= 5 and H = 320 that is
+// 320 VGPRs of the 512 a one-wave-per-SIMD workgroup owns, and the LSTM step stops touching L2 altogether.
+template <int NR, int RESQ = 0>
 __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArgs g) {
   extern __shared__ __attribute__((aligned(16))) float gam_smem_rc[];
   const GamRnntArgs& a = g.a;
@@ -125,6 +133,11 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
   // W_pred slice: P k-parts per row when the slice is small
   const int P = nP >= 128 ? 1 : (256 / nP < 8 ? 256 / nP : 8);
   const int HQ = H / 4, JQ = JH / 4;
+  f32x4 wres[RESQ > 0 ? RESQ : 1];
+  if constexpr (RESQ > 0) {
+#pragma unroll
+    for (int q = 0; q < RESQ; ++q) wres[q] = *reinterpret_cast<const f32x4*>(g.whh_q + ((size_t)q * 4 * H + grow[0]) * 4);
+  }
 
   int label = V;       // gate_tab row V: zero embedding (predict(None, None), decoder.py:97-100)
   int n_out = 0, n_dump = 0;
@@ -141,6 +154,16 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
         float acc[NR];
 #pragma unroll
         for (int j = 0; j < NR; ++j) acc[j] = a.gate_tab[(size_t)label * 4 * H + grow[j]];
+        if constexpr (RESQ > 0) {
+#pragma unroll
+          for (int q = 0; q < RESQ; ++q) {
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(h_s + 4 * q);
+            acc[0] = fmaf(wres[q].x, hv.x, acc[0]);
+            acc[0] = fmaf(wres[q].y, hv.y, acc[0]);
+            acc[0] = fmaf(wres[q].z, hv.z, acc[0]);
+            acc[0] = fmaf(wres[q].w, hv.w, acc[0]);
+          }
+        } else {
         // float4 loads in flight per row slot: the step is L2-LATENCY bound (each batch of loads is one round trip),
         // so as many as the registers hold -- ~160 VGPRs of weights per thread
         constexpr int KU = NR == 1 ? 40 : (NR == 2 ? 20 : (NR == 3 ? 12 : (NR == 5 ? 8 : 4)));
@@ -165,6 +188,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
               }
             }
           }
+        }
         }
 #pragma unroll
         for (int j = 0; j < NR; ++j)
@@ -283,39 +307,25 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       const float* wr = (wout_l != nullptr ? wout_l + (size_t)(vc - v0) * WLD : a.wout + (size_t)vc * JH) + 4 * lg4;
       const float* zr = zw + li * ZLD + 4 * lg4;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int k0 = 0; k0 + 128 <= JH; k0 += 128) {   // 8 x 16-byte loads in flight per lane (L2-streamed slice: one round trip per 128 k)
-        float4 wf[8];
+      // all of the tile's W_out reads in flight at once (JH / 16 x 16 bytes per lane): with the slice streamed from L2
+      // (SentencePiece vocabularies) every batch of loads is one L2 round trip, and a wave runs several tiles
+      constexpr int MAXU = GAM_RNNT_MAXH / 16, UB = RESQ > 0 ? 10 : 32;   // (register-resident W_hh leaves room for 10 at a time)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) wf[u] = *reinterpret_cast<const float4*>(wr + k0 + 16 * u);
+      for (int u0 = 0; u0 < MAXU; u0 += UB) {
+        if (16 * u0 + 16 > JH) break;
+        float4 wf[UB];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float4 zf = *reinterpret_cast<const float4*>(zr + k0 + 16 * u);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.x, wf[u].x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf[u].y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf[u].z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf[u].w, acc, 0, 0, 0);
+        for (int u = 0; u < UB; ++u) wf[u] = *reinterpret_cast<const float4*>(wr + (16 * (u0 + u) + 16 <= JH ? 16 * (u0 + u) : 0));
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          if (16 * (u0 + u) + 16 <= JH) {
+            const float4 zf = *reinterpret_cast<const float4*>(zr + 16 * (u0 + u));
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.x, wf[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf[u].w, acc, 0, 0, 0);
+          }
         }
-      }
-      for (int k0 = JH / 128 * 128; k0 + 64 <= JH; k0 += 64) {
-        float4 wf[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const float4*>(wr + k0 + 16 * u);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float4 zf = *reinterpret_cast<const float4*>(zr + k0 + 16 * u);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.x, wf[u].x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf[u].y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf[u].z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf[u].w, acc, 0, 0, 0);
-        }
-      }
-      for (int k0 = JH / 64 * 64; k0 + 16 <= JH; k0 += 16) {
-        const float4 zf = *reinterpret_cast<const float4*>(zr + k0);
-        const float4 wf = *reinterpret_cast<const float4*>(wr + k0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.x, wf.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf.w, acc, 0, 0, 0);
       }
       if (v < v1) {   // C/D: col = lane&15 = class, row = 4*(lane>>4) + r = frame
         const float bo = a.bout[v];
