@@ -93,8 +93,16 @@ def make_gather(kind: str, rank: int, n_ranks: int, dev: torch.device):
             box = [uid]
             dist.broadcast_object_list(box, src=0)
             return box[0]
-        comm = shard.HipComm(rank, n_ranks, dev, exchange)
-        return comm.gather, "gam_gather_ids (RCCL ncclAllGather behind the C ABI)"
+        try:
+            comm = shard.HipComm(rank, n_ranks, dev, exchange)
+            ok = 1
+        except Exception as e:   # the line must still be produced: fall back to torch's own RCCL group, and say so
+            print(f"[bench] rank {rank}: gam_comm_create failed ({e}); using torch.distributed for the gather", file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank takes the same path
+        if int(flag.item()) == 1:
+            return comm.gather, "gam_gather_ids (RCCL ncclAllGather behind the C ABI)"
 
     def tg(index, counts, ids, frames):
         mv = lambda t: None if t is None else t.to(dev)  # noqa: E731
@@ -284,7 +292,9 @@ def main():
             cpu_sample = (host_batches[mine[0]][0], host_batches[mine[0]][1], host_batches[mine[0]][2])
 
         def step():
-            res = shard.run_sharded(batches, decode_batch, rank, n_ranks, gather, cap, my_batches=mine)
+            # batch n is launched before batch n-1's ids are copied back (shard.run_sharded, collect=)
+            res = shard.run_sharded(batches, decode_dev, rank, n_ranks, gather, cap, my_batches=mine, collect=lambda h: ragged_host(*h))
+            eng.range_flag()
             return res if rank != 0 else [(i, f, tok.decode(i)) for i, f in res]     # detokenised like the package API
         workload = (f"{model_name} (V = 1025), {n_utts} utterances with durations U(5 s, 20 s) sorted into 32-utterance batches "
                     f"dealt to {n_ranks} rank(s) ({len(mine)} batches on rank 0), frontend + encoder + RNN-T greedy + ids to host + "
@@ -303,11 +313,15 @@ def main():
         tok = model.decoding.tokenizer
 
         def step():
-            rows, o = [], 0
+            rows, pending = [], None
             for wav_b, len_b in BatchFeeder(my_segs, fr_bs, dev):            # pinned, double-buffered H2D
-                for i, f in decode_batch(wav_b, len_b):
-                    rows.append((my_idx[o], i, f))
-                    o += 1
+                out_b = decode_dev(wav_b, len_b)                              # launched; collected one batch later
+                if pending is not None:
+                    rows += [(my_idx[len(rows) + k], i, f) for k, (i, f) in enumerate(ragged_host(*pending))]
+                pending = out_b
+            if pending is not None:
+                rows += [(my_idx[len(rows) + k], i, f) for k, (i, f) in enumerate(ragged_host(*pending))]
+            eng.range_flag()
             res = shard.unpack_results(*gather(*shard.pack_results(rows, per_rank, cap)), len(segs))
             return res if rank != 0 else [(tok.decode(i), bounds[k]) for k, (i, f) in enumerate(res)]
         workload = (f"{model_name} longform: {args.longform_seconds} s of audio -> {len(segs)} chunks (reference packer 22/15/30/0.2 s) -> "

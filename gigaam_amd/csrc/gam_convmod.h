@@ -230,6 +230,93 @@ __global__ __launch_bounds__(256) void gam_convmod_ln_kernel(GamConvModArgs a) {
   }
 }
 
+// ---- LayerNorm variant, small kernels (v3 models: k = 5): block = 16 frames x all channels, a thread owns 4
+// consecutive channels.  The depthwise conv mixes time only, so the thread convolves its own channels straight from
+// the rows it loaded (no LDS tile); only the per-frame mean / variance over channels crosses threads.  16-byte loads
+// and stores, all (16 + KS - 1) x 2 loads of a thread in flight, 25 % halo instead of 50 %.
+template <int KS>
+__global__ __launch_bounds__(256) void gam_convmod_ln4_kernel(GamConvModArgs a) {
+  constexpr int TT = 16, PAD = (KS - 1) / 2, ROWS = TT + KS - 1;
+  __shared__ float red[4][TT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y, t0 = blockIdx.x * TT;
+  const bool live = tid * 4 < a.d;                 // d % 4 == 0, d <= 1024
+  const int c = live ? tid * 4 : 0;
+  int klen = a.lens[b];
+  klen = klen < a.Tv ? klen : a.Tv;
+  const size_t rowbase = (size_t)b * a.Ta;
+  f32x4 ua[ROWS], ub[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const int t = t0 - PAD + r;
+    const int tc = t < 0 ? 0 : (t < a.Ta ? t : a.Ta - 1);
+    const float* up = a.u + (rowbase + tc) * (size_t)(2 * a.d);
+    ua[r] = *reinterpret_cast<const f32x4*>(up + c);
+    ub[r] = *reinterpret_cast<const f32x4*>(up + a.d + c);
+  }
+  f32x4 w[KS];
+#pragma unroll
+  for (int k = 0; k < KS; ++k)
+    w[k] = (f32x4){a.dw_w[(size_t)c * KS + k], a.dw_w[(size_t)(c + 1) * KS + k], a.dw_w[(size_t)(c + 2) * KS + k],
+                   a.dw_w[(size_t)(c + 3) * KS + k]};
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(a.dw_b + c);
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {   // GLU, padded frames enter the taps as 0 (a select, not a branch)
+    const int t = t0 - PAD + r;
+    const float m = (t >= 0 && t < klen) ? 1.0f : 0.0f;
+    ua[r] = (f32x4){m * ua[r].x * gam_sigmoid(ub[r].x), m * ua[r].y * gam_sigmoid(ub[r].y), m * ua[r].z * gam_sigmoid(ub[r].z),
+                    m * ua[r].w * gam_sigmoid(ub[r].w)};
+  }
+  f32x4 y[TT];
+#pragma unroll
+  for (int i = 0; i < TT; ++i) {
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      acc.x = fmaf(w[k].x, ua[i + k].x, acc.x);
+      acc.y = fmaf(w[k].y, ua[i + k].y, acc.y);
+      acc.z = fmaf(w[k].z, ua[i + k].z, acc.z);
+      acc.w = fmaf(w[k].w, ua[i + k].w, acc.w);
+    }
+    y[i] = acc + bias;
+  }
+  // per-frame mean, then variance, over the d channels (two passes like native_layer_norm)
+  float mean[TT], rstd[TT];
+#pragma unroll
+  for (int i = 0; i < TT; ++i) {
+    float s = live ? (y[i].x + y[i].y) + (y[i].z + y[i].w) : 0.f;
+    s = gam_wave_sum(s);
+    if (lane == 0) red[wave][i] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TT; ++i) mean[i] = (red[0][i] + red[1][i] + red[2][i] + red[3][i]) / (float)a.d;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TT; ++i) {
+    const float d0 = y[i].x - mean[i], d1 = y[i].y - mean[i], d2 = y[i].z - mean[i], d3 = y[i].w - mean[i];
+    float s = live ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
+    s = gam_wave_sum(s);
+    if (lane == 0) red[wave][i] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < TT; ++i) rstd[i] = 1.0f / sqrtf((red[0][i] + red[1][i] + red[2][i] + red[3][i]) / (float)a.d + a.eps);
+  if (!live) return;
+  const f32x4 gm = *reinterpret_cast<const f32x4*>(a.n_scale + c);
+  const f32x4 be = *reinterpret_cast<const f32x4*>(a.n_shift + c);
+#pragma unroll
+  for (int i = 0; i < TT; ++i) {
+    const int t = t0 + i;
+    if (t < a.Ta) {
+      const float v0 = gam_silu((y[i].x - mean[i]) * rstd[i] * gm.x + be.x), v1 = gam_silu((y[i].y - mean[i]) * rstd[i] * gm.y + be.y);
+      const float v2 = gam_silu((y[i].z - mean[i]) * rstd[i] * gm.z + be.z), v3 = gam_silu((y[i].w - mean[i]) * rstd[i] * gm.w + be.w);
+      if (a.z_split) gam_range_note(a.range_flag, v0, v1, v2, v3);
+      gam_store4(a.z, (rowbase + t) * (size_t)a.d, c, v0, v1, v2, v3, a.z_split);
+    }
+  }
+}
+
 static inline hipError_t gam_launch_convmod(const GamConvModArgs& a, int layer_norm, hipStream_t s) {
   if (!layer_norm) {
     if (a.d % 64 != 0) return hipErrorInvalidValue;
@@ -241,7 +328,11 @@ static inline hipError_t gam_launch_convmod(const GamConvModArgs& a, int layer_n
   } else {
     if (a.d > 1024) return hipErrorInvalidValue;
     dim3 grid(gam_cdiv(a.Ta, 8), a.B);
-    if (a.ks == 5) {
+    if ((a.ks == 5 || a.ks == 9) && a.d % 4 == 0) {   // thread-owns-4-channels kernel, 16-frame blocks
+      dim3 g4(gam_cdiv(a.Ta, 16), a.B);
+      if (a.ks == 5) hipLaunchKernelGGL(gam_convmod_ln4_kernel<5>, g4, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(gam_convmod_ln4_kernel<9>, g4, dim3(256), 0, s, a);
+    } else if (a.ks == 5) {
       const size_t sm = ((8 + 4) * a.d + 32) * sizeof(float);
       hipLaunchKernelGGL(gam_convmod_ln_kernel<5>, grid, dim3(256), sm, s, a);
     } else if (a.ks == 31) {

@@ -71,6 +71,7 @@ struct GamGemmArgs {
   // 128x128 kernel splits it.  null = none (always null on the exact-fp32 path).
   const float* a_rs;
   int* range_flag;      // c_split outputs carry no row scale: values beyond fp16's range set this flag (may be null)
+  int prio;             // LDS-DMA GEMM: s_setprio 1 for the later-dispatched half of the waves (GAM_SP_PRIO, A/B switch)
 };
 
 #define GAM_GEMM_BM 128

@@ -57,11 +57,19 @@ class CTCGreedyDecoding:
         self.blank_id = len(self.tokenizer)
 
     @torch.inference_mode()
-    def decode(self, head: CTCHead, encoded: Tensor, lengths: Tensor) -> List[Tuple[str, List[int], List[int]]]:
+    def decode_device(self, head: CTCHead, encoded: Tensor, lengths: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        """The device half of ``decode``: (ids, frames, counts) i32 tensors on the GPU, no host sync -- a driver
+        can launch the next batch before it looks at this one (``finish``)."""
         c = head.num_classes
         assert c == len(self.tokenizer) + 1, f"Num classes {c} != len(vocab)+1 {len(self.tokenizer)+1}"
-        ids, frames, counts = head.engine.ctc_greedy(encoded, lengths)
+        return head.engine.ctc_greedy(encoded, lengths)
+
+    def finish(self, ids: Tensor, frames: Tensor, counts: Tensor) -> List[Tuple[str, List[int], List[int]]]:
         return [(self.tokenizer.decode(i), i, f) for i, f in _ragged(ids, frames, counts)]
+
+    @torch.inference_mode()
+    def decode(self, head: CTCHead, encoded: Tensor, lengths: Tensor) -> List[Tuple[str, List[int], List[int]]]:
+        return self.finish(*self.decode_device(head, encoded, lengths))
 
 
 class RNNTGreedyDecoding:
@@ -71,6 +79,12 @@ class RNNTGreedyDecoding:
         self.max_symbols = max_symbols_per_step
 
     @torch.inference_mode()
-    def decode(self, head: RNNTHead, encoded: Tensor, enc_len: Tensor) -> List[Tuple[str, List[int], List[int]]]:
-        ids, frames, counts = head.engine.rnnt_greedy(encoded, enc_len, self.max_symbols)
+    def decode_device(self, head: RNNTHead, encoded: Tensor, enc_len: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+        return head.engine.rnnt_greedy(encoded, enc_len, self.max_symbols)
+
+    def finish(self, ids: Tensor, frames: Tensor, counts: Tensor) -> List[Tuple[str, List[int], List[int]]]:
         return [(self.tokenizer.decode(i), i, f) for i, f in _ragged(ids, frames, counts)]
+
+    @torch.inference_mode()
+    def decode(self, head: RNNTHead, encoded: Tensor, enc_len: Tensor) -> List[Tuple[str, List[int], List[int]]]:
+        return self.finish(*self.decode_device(head, encoded, enc_len))

@@ -57,6 +57,8 @@ def instantiate(node: Any) -> Any:
 
 
 class GigaAM(nn.Module):
+    _check_range = True   # forward() reads the split-fp16 range flag (one 4-byte D2H + sync) and falls back to fp32
+
     def __init__(self, cfg: Any):
         super().__init__()
         self.cfg = cfg
@@ -94,7 +96,7 @@ class GigaAM(nn.Module):
         features, feature_lengths = self.preprocessor(features, feature_lengths)
         out = self.encoder(features, feature_lengths)
         eng = getattr(self.encoder, "engine", None)
-        if eng is not None and eng.gemm_mode == "f16x3" and eng.range_flag():
+        if self._check_range and eng is not None and eng.gemm_mode == "f16x3" and eng.range_flag():
             # an activation outside fp16's range reached a split-fp16 GEMM operand (include/gigaam_hip.h,
             # gam_range_flag): the batch is repeated on the exact-fp32 MFMA path, which has no such limit
             import warnings
@@ -225,15 +227,70 @@ class GigaAMASR(GigaAM):
             return LongformTranscriptionResult(segments=[])
         from .feeder import BatchFeeder
 
+        # One-batch software pipeline: the kernels of batch n are launched (no host sync) BEFORE the decoded ids of
+        # batch n-1 are copied back and detokenised, so the D2H wait, the tokenizer and the feeder's staging of the
+        # next batch all run while the GPU works.  (The reference syncs per batch: model.py:230-236.)  The range flag
+        # of the split-fp16 GEMMs is read once, at the end: if it ever fired the file is redone on the fp32 path.
         result: List[Segment] = []
         idx = 0
-        for wav, lens in BatchFeeder(segments, fr_batch_size, self._device):   # pinned, double-buffered H2D
-            for text, words in self.transcribe_batch(wav, lens, word_timestamps):
+
+        def emit(pending) -> None:
+            nonlocal idx
+            dev_out, lens, wl, el = pending
+            decoded = self.decoding.finish(*dev_out)
+            if word_timestamps:
+                from .timestamps_utils import compute_frame_shift, frames_to_words
+                wl_h, el_h = wl.cpu().tolist(), el.cpu().tolist()
+            for i, (text, ids, frames) in enumerate(decoded):
                 start, end = boundaries[idx]
                 idx += 1
                 if word_timestamps:
+                    words = frames_to_words(self.decoding.tokenizer, ids, frames, compute_frame_shift(int(wl_h[i]), int(el_h[i])))
                     shifted = [Word(text=w.text, start=round(w.start + start, 3), end=round(w.end + start, 3)) for w in words or []]
                     result.append(Segment(text=text, start=start, end=end, words=shifted))
                 else:
                     result.append(Segment(text=text, start=start, end=end))
+
+        def run() -> None:
+            nonlocal idx
+            result.clear()
+            idx = 0
+            pending = None
+            prev_check, self._check_range = self._check_range, False
+            try:
+                for wav, lens in BatchFeeder(segments, fr_batch_size, self._device):   # pinned, double-buffered H2D
+                    wav = wav.to(self._dtype)
+                    encoded, encoded_len = self.forward(wav, lens)
+                    dev_out = self.decoding.decode_device(self.head, encoded, encoded_len)
+                    if pending is not None:
+                        emit(pending)
+                    pending = (dev_out, lens, lens, encoded_len)
+                if pending is not None:
+                    emit(pending)
+            finally:
+                self._check_range = prev_check
+
+        if type(self).transcribe_batch is not GigaAMASR.transcribe_batch or "transcribe_batch" in self.__dict__:
+            # a caller replaced transcribe_batch (tests do, to script the decode): keep the plain per-batch loop
+            for wav, lens in BatchFeeder(segments, fr_batch_size, self._device):
+                for text, words in self.transcribe_batch(wav, lens, word_timestamps):
+                    start, end = boundaries[idx]
+                    idx += 1
+                    if word_timestamps:
+                        shifted = [Word(text=w.text, start=round(w.start + start, 3), end=round(w.end + start, 3)) for w in words or []]
+                        result.append(Segment(text=text, start=start, end=end, words=shifted))
+                    else:
+                        result.append(Segment(text=text, start=start, end=end))
+            return LongformTranscriptionResult(segments=result)
+        eng = self.encoder.engine
+        run()
+        if eng.gemm_mode == "f16x3" and eng.range_flag():
+            import warnings
+            warnings.warn("gigaam_amd: activation beyond the split-fp16 GEMM range; the file was recomputed with "
+                          "GAM_GEMM_F32", RuntimeWarning, stacklevel=2)
+            eng.set_gemm_mode("f32")
+            try:
+                run()
+            finally:
+                eng.set_gemm_mode("f16x3")
         return LongformTranscriptionResult(segments=result)

@@ -44,18 +44,19 @@ def deal(n_batches: int, rank: int, n_ranks: int, snake: bool = True) -> List[in
 def pack_results(rows: Sequence[Tuple[int, Sequence[int], Sequence[int]]], n_rows: int, cap: int):
     """Local decode results [(global_index, ids, frames)] -> fixed-shape buffers for the gather:
     index i32 [n_rows] (-1 = unused row), counts i32 [n_rows], ids / frames i32 [n_rows, cap]."""
-    index = torch.full((n_rows,), -1, dtype=torch.int32)
-    counts = torch.zeros((n_rows,), dtype=torch.int32)
-    ids = torch.zeros((n_rows, cap), dtype=torch.int32)
-    frames = torch.zeros((n_rows, cap), dtype=torch.int32)
+    import numpy as np
+    index = np.full((n_rows,), -1, dtype=np.int32)
+    counts = np.zeros((n_rows,), dtype=np.int32)
+    ids = np.zeros((n_rows, cap), dtype=np.int32)
+    frames = np.zeros((n_rows, cap), dtype=np.int32)
     assert len(rows) <= n_rows
     for r, (g, i, f) in enumerate(rows):
         n = len(i)
         assert n <= cap and len(f) == n
         index[r], counts[r] = g, n
-        ids[r, :n] = torch.as_tensor(list(i), dtype=torch.int32)
-        frames[r, :n] = torch.as_tensor(list(f), dtype=torch.int32)
-    return index, counts, ids, frames
+        ids[r, :n] = i
+        frames[r, :n] = f
+    return tuple(torch.from_numpy(x) for x in (index, counts, ids, frames))
 
 
 def unpack_results(index: Tensor, counts: Tensor, ids: Tensor, frames: Tensor, n_total: int):
@@ -78,21 +79,38 @@ def unpack_results(index: Tensor, counts: Tensor, ids: Tensor, frames: Tensor, n
 
 
 def run_sharded(batches: Sequence[Tuple[Tensor, Tensor, Sequence[int]]], decode_batch: Callable, rank: int, n_ranks: int,
-                gather: Callable, cap: int, snake: bool = True, my_batches: Optional[Sequence[int]] = None):
+                gather: Callable, cap: int, snake: bool = True, my_batches: Optional[Sequence[int]] = None,
+                collect: Optional[Callable] = None):
     """Drive one rank's share of ``batches`` [(wav, len, global_indices)] through ``decode_batch(wav, len) ->
     [(ids, frames)]`` and gather everything: returns [(ids, frames)] for ALL utterances in global order (on every
     rank).  ``gather(index, counts, ids, frames) -> the same four, concatenated rank-major``; it is called exactly
-    once, after the last local batch -- the path's one exchange."""
+    once, after the last local batch -- the path's one exchange.
+
+    With ``collect``, ``decode_batch`` only LAUNCHES a batch (returns an opaque handle, no host sync) and
+    ``collect(handle) -> [(ids, frames)]`` brings it to the host; batch n is launched before batch n-1 is collected,
+    so the D2H wait and the host-side list building overlap the GPU's work on the next batch."""
     mine = list(my_batches) if my_batches is not None else deal(len(batches), rank, n_ranks, snake)
     n_total = sum(len(b[2]) for b in batches)
     # every rank contributes the same number of rows (fixed-size all-gather): the largest share
     per_rank = max(sum(len(batches[j][2]) for j in deal(len(batches), r, n_ranks, snake)) for r in range(n_ranks))
     rows = []
+
+    def take(res, gidx):
+        assert len(res) == len(gidx)
+        rows.extend((int(g), i, f) for g, (i, f) in zip(gidx, res))
+
+    pending = None
     for j in mine:
         wav, wlen, gidx = batches[j]
-        res = decode_batch(wav, wlen)
-        assert len(res) == len(gidx)
-        rows += [(int(g), i, f) for g, (i, f) in zip(gidx, res)]
+        out = decode_batch(wav, wlen)
+        if collect is None:
+            take(out, gidx)
+        else:
+            if pending is not None:
+                take(collect(pending[0]), pending[1])
+            pending = (out, gidx)
+    if pending is not None:
+        take(collect(pending[0]), pending[1])
     packed = pack_results(rows, per_rank, cap)
     return unpack_results(*gather(*packed), n_total)
 
@@ -112,12 +130,15 @@ class HipComm:
         self.rank, self.world = rank, world
         self.device = torch.device(device)
         buf = C.create_string_buffer(128)
+        err = None
         if rank == 0:
             rc = self.lib.gam_comm_unique_id(buf)
             if rc != 0:
-                raise _lib.GigaAMHipError(f"gam_comm_unique_id failed ({rc}): {self.lib.gam_comm_last_error(None).decode()}")
-        uid = exchange_id(buf.raw if rank == 0 else None)
-        assert len(uid) == 128
+                err = f"gam_comm_unique_id failed ({rc}): {self.lib.gam_comm_last_error(None).decode()}"
+        # rank 0 always takes part in the exchange (an empty id tells the others it failed: nobody is left waiting)
+        uid = exchange_id((b"" if err else buf.raw) if rank == 0 else None)
+        if err or len(uid) != 128:
+            raise _lib.GigaAMHipError(err or "rank 0 could not create an RCCL id")
         self._c = C.c_void_p()
         rc = self.lib.gam_comm_create(uid, rank, world, self.device.index or 0, C.byref(self._c))
         self._check(rc, "gam_comm_create")

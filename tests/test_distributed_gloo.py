@@ -73,6 +73,11 @@ def _worker(rank, world, port, q):
         return fake_decode(wav, wlen)
     res4 = shard.run_sharded(batches, dec, rank, world, shard.torch_gather, cap=16)
     n_decoded4 = sum(len(s) for s in seen)
+    # the launch / collect form (one-batch lag) must give the same thing
+    order = []
+    res4b = shard.run_sharded(batches, lambda w, l: (order.append("launch"), (w, l))[1], rank, world, shard.torch_gather, cap=16,
+                              collect=lambda h: (order.append("collect"), fake_decode(*h))[1])
+    assert res4b == res4 and order[:3] == ["launch", "launch", "collect"][: len(order)]
     # (c) config-5 style: file-order batches of 16 dealt round-robin, rows packed with their global index
     segs = [torch.randn(30 + 7 * i) for i in range(41)]
     fr_bs = 16
