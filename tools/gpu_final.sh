@@ -1,24 +1,38 @@
 #!/bin/bash
-# Final measurement visit of the round: tests, smoke, bench (both modes + a 1-rank torchrun launch of the
-# distributed path), rocprof trace + PMC passes, all five BASELINE configurations.
+# Full measurement visit: GPU tests (with the measured-error report), smoke, the driver's bench command, a 1-rank
+# torchrun launch of the distributed path, rocprofv3 kernel trace + PMC passes (separate runs, as the guide
+# prescribes), and all five BASELINE configurations.  Everything lands under gpurun_out/$TAG/.
+#   gpurun --timeout 2400 -- 'bash tools/gpu_final.sh r02_final'
+TAG=${1:-final}
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD
-mkdir -p gpurun_out
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
 export TMPDIR=/tmp
-( time timeout 900 python -m pytest tests -q -m gpu ) > gpurun_out/pytest_gpu.log 2>&1
-( timeout 300 python __graft_entry__.py --smoke ) > gpurun_out/smoke.log 2>&1
-( timeout 300 python bench.py --steps 10 --warmup 3 ) > gpurun_out/bench.log 2>&1
-( timeout 300 python bench.py --steps 5 --warmup 2 --gemm f32 --cpu-utts 0 ) > gpurun_out/bench_f32.log 2>&1
-( timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --cpu-utts 0 ) > gpurun_out/bench_torchrun1.log 2>&1
+export GAM_TEST_REPORT=$OUT/measured_errors.jsonl
+rm -f $GAM_TEST_REPORT
+( time timeout 1200 python -m pytest tests -q -m gpu ) > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+( timeout 300 python __graft_entry__.py --smoke ) > $OUT/smoke.log 2>&1; echo "smoke rc=$?"
+( timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench.log 2> $OUT/bench.err; echo "bench rc=$?"
+( timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --cpu-utts 0 --no-f32-leg ) > $OUT/bench_torchrun1.log 2>&1; echo "torchrun rc=$?"
 cd /tmp
-B="python $R/bench.py --steps 1 --warmup 1 --cpu-utts 0 --no-profile"
-( timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/pf_trace -o b -- python $R/bench.py --steps 3 --warmup 1 --cpu-utts 0 --no-profile ) > $R/gpurun_out/pf_trace.log 2>&1
-( timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pf_fetch -o b -- $B ) > $R/gpurun_out/pf_fetch.log 2>&1
-( timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pf_write -o b -- $B ) > $R/gpurun_out/pf_write.log 2>&1
-( timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $R/gpurun_out/pf_sq -o b -- $B ) > $R/gpurun_out/pf_sq.log 2>&1
+B="python $R/bench.py --steps 1 --warmup 1 --cpu-utts 0 --no-profile --no-f32-leg"
+( timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_trace -o b -- python $R/bench.py --steps 5 --warmup 2 --cpu-utts 0 --no-f32-leg ) > $OUT/pf_trace.log 2>&1
+( timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pf_fetch -o b -- $B ) > $OUT/pf_fetch.log 2>&1
+( timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pf_write -o b -- $B ) > $OUT/pf_write.log 2>&1
+( timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pf_sq -o b -- $B ) > $OUT/pf_sq.log 2>&1
+( timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_trace_c3 -o b -- python $R/bench.py --config 3 --steps 3 --warmup 1 --cpu-utts 0 --no-f32-leg ) > $OUT/pf_trace_c3.log 2>&1
 cd $R
-( timeout 600 python tools/bench_configs.py --only 1,3,4,5 ) > gpurun_out/configs.log 2>&1
-tail -3 gpurun_out/pytest_gpu.log; tail -1 gpurun_out/smoke.log
-for f in bench bench_f32 bench_torchrun1; do tail -1 gpurun_out/$f.log | cut -c1-200; done
-tail -6 gpurun_out/configs.log | cut -c1-260
-ls gpurun_out/pf_*/
+for n in trace fetch write sq trace_c3; do
+  DB=$(find $OUT/pf_$n -name "*.db" | head -1)
+  [ -n "$DB" ] && python tools/rocpd_summary.py $DB $OUT/${n}_summary.txt "rocprofv3 pass '$n' of bench.py (config 2, f16x3; trace_c3: config 3)" > /dev/null 2>&1
+done
+FD=$(find $OUT/pf_fetch -name "*.db" | head -1); WD=$(find $OUT/pf_write -name "*.db" | head -1)
+[ -n "$FD" ] && [ -n "$WD" ] && python tools/pmc_traffic.py $FD $WD $OUT/pmc_traffic_f16x3.json > $OUT/pmc_traffic.log 2>&1
+find $OUT -name "*.db" -delete
+( timeout 900 python tools/bench_configs.py --only 1,3,4,5 --out $OUT/configs.jsonl ) > $OUT/configs.log 2>&1; echo "configs rc=$?"
+tail -3 $OUT/pytest_gpu.log; tail -1 $OUT/smoke.log
+grep -a "^{" $OUT/bench.log | cut -c1-400
+grep -a "^{" $OUT/bench_torchrun1.log | cut -c1-200
+cat $OUT/configs.log | cut -c1-300
+head -12 $OUT/trace_summary.txt | cut -c1-150
