@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=20.0)
     ap.add_argument("--utts-per-gpu", type=int, default=128, help="config 4, weak scaling")
     ap.add_argument("--longform-seconds", type=int, default=3600, help="config 5")
+    ap.add_argument("--fr-batch", type=int, default=16, help="config 5: chunks per batch (the reference's fr_batch_size default)")
     ap.add_argument("--layers", type=int, default=-1, help="debug only: fewer layers INVALIDATES the number")
     ap.add_argument("--cpu-utts", type=int, default=-1, help="utterances in the CPU-oracle leg (0 = skip; default: 32 for config 2, 4 otherwise)")
     ap.add_argument("--rnnt-blank-bias", type=float, default=None,
@@ -208,6 +209,9 @@ def main():
     n_ranks = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback)")
+    # host side of the timed region: a handful of small CPU tensor ops.  Left at the default (one OpenMP thread per
+    # core) they spin on every core of the box and, under a CPU quota, get the launching thread throttled mid-batch.
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
     torch.cuda.set_device(local_rank)
     if n_ranks > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -302,7 +306,7 @@ def main():
     else:
         from gigaam_amd.feeder import BatchFeeder
         segs, bounds = workloads.config5_segments(args.longform_seconds)
-        fr_bs = 16
+        fr_bs = args.fr_batch
         n_b = (len(segs) + fr_bs - 1) // fr_bs
         mine = shard.deal(n_b, rank, n_ranks, snake=False)      # round-robin, in file order
         my_segs = [s for j in mine for s in segs[j * fr_bs:(j + 1) * fr_bs]]
@@ -312,20 +316,31 @@ def main():
         audio_s = float(args.longform_seconds)
         tok = model.decoding.tokenizer
 
+        feeder = BatchFeeder(my_segs, fr_bs, dev) if my_segs else []       # pinned staging buffers: allocated once
+
+        trace = os.environ.get("GAM_BENCH_TRACE")   # debug: host timestamps per batch (ms since the step began)
+
         def step():
             rows, pending = [], None
-            for wav_b, len_b in BatchFeeder(my_segs, fr_bs, dev):            # pinned, double-buffered H2D
+            t_s, marks = time.perf_counter(), []
+            for wav_b, len_b in feeder:                                       # pinned, double-buffered H2D
+                t_a = time.perf_counter()
                 out_b = decode_dev(wav_b, len_b)                              # launched; collected one batch later
+                t_b = time.perf_counter()
                 if pending is not None:
                     rows += [(my_idx[len(rows) + k], i, f) for k, (i, f) in enumerate(ragged_host(*pending))]
                 pending = out_b
+                if trace:
+                    marks.append((round((t_a - t_s) * 1e3, 1), round((t_b - t_a) * 1e3, 1), round((time.perf_counter() - t_b) * 1e3, 1), tuple(wav_b.shape)))
+            if trace:
+                print("[trace] (staged_at, launch_ms, collect_prev_ms, shape):", marks, file=sys.stderr)
             if pending is not None:
                 rows += [(my_idx[len(rows) + k], i, f) for k, (i, f) in enumerate(ragged_host(*pending))]
             eng.range_flag()
             res = shard.unpack_results(*gather(*shard.pack_results(rows, per_rank, cap)), len(segs))
             return res if rank != 0 else [(tok.decode(i), bounds[k]) for k, (i, f) in enumerate(res)]
         workload = (f"{model_name} longform: {args.longform_seconds} s of audio -> {len(segs)} chunks (reference packer 22/15/30/0.2 s) -> "
-                    f"batches of 16 dealt round-robin to {n_ranks} rank(s), streamed from host memory through the pinned "
+                    f"batches of {fr_bs} dealt round-robin to {n_ranks} rank(s), streamed from host memory through the pinned "
                     "double-buffered feeder, CTC greedy, gather, detokenise")
 
     # ---- timing: W warm-up steps, then EXACTLY K steps between barrier + synchronize pairs; max over ranks

@@ -97,6 +97,8 @@ struct gam_handle {
   float *jn_enc_w = nullptr, *jn_enc_b = nullptr, *jn_pred_t = nullptr, *jn_pred_b = nullptr;
   float *jn_out_w = nullptr, *jn_out_b = nullptr, *lstm_whh_t = nullptr, *lstm_tab = nullptr;
   float *lstm_whh_q = nullptr, *jn_pred_q = nullptr;   // [k/4][row][4] re-layouts for the cluster decode kernel
+  int use_rowscale = 1;         // GAM_ROWSCALE=0: no per-row pre-scale of the LayerNorm-produced GEMM operands (A/B switch)
+  int use_range = 1;            // GAM_RANGE=0: no range guard on the unscaled operands (A/B switch)
   int rnnt_cluster = -1;        // GAM_RNNT_CLUSTER: 0 = one workgroup per utterance, N = force N per utterance, -1 = auto
   DevBuf rnnt_x;                // hand-off granules + status word of the cluster kernel
 
@@ -285,7 +287,8 @@ struct ProfScope {
 
 int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls = GAM_PF_GEMM, const W16* w16 = nullptr) {
   GamGemmArgs a = a_in;
-  a.range_flag = h->range_flag;
+  a.range_flag = h->use_range ? h->range_flag : nullptr;
+  if (h->gemm_mode != GAM_GEMM_F16X3) a.c_guard = 0;   // fp32 consumers have no range limit
   if (h->gemm_mode != GAM_GEMM_F16X3 || w16 == nullptr || w16->hi == nullptr) a.a_rs = nullptr;   // exact-fp32 path: A is never scaled
   ProfScope ps(h, s, cls, 2.0 * (double)a.M * (double)a.N * (double)a.K);
   if (ps.ev) {   // unique bytes: A (overlapping rows counted once), W, C (+ residual)
@@ -374,6 +377,8 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   if (const char* e = getenv("GAM_SPLITK")) h->use_splitk = atoi(e);
   if (const char* e = getenv("GAM_GRAPH")) h->use_graph = atoi(e);
   if (const char* e = getenv("GAM_RNNT_CLUSTER")) h->rnnt_cluster = atoi(e);
+  if (const char* e = getenv("GAM_ROWSCALE")) h->use_rowscale = atoi(e);
+  if (const char* e = getenv("GAM_RANGE")) h->use_range = atoi(e);
   if (const char* e = getenv("GAM_GEMM_MODE")) h->gemm_mode = (strcmp(e, "f32") == 0) ? GAM_GEMM_F32 : GAM_GEMM_F16X3;
   const gam_config& c = h->cfg;
   if (c.d_model <= 0 || c.n_heads <= 0 || c.d_model % c.n_heads != 0)
@@ -871,6 +876,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     g.a_mode = 1; g.conv_fp = FP; g.conv_c = C; g.conv_f2 = F2;
     g.lens = len2; g.rpb = Ta * F2; g.fdiv = F2;
     if (sp && C % 32 == 0) { sp_a(g); g.c_split = 1; }
+    g.c_guard = 1;
     if (int r = gemm(h, s, g, GAM_ACT_RELU, GAM_PF_CONV2, &h->s_c2)) return r;
     GamGemmArgs l = gemm_args(h->c2.p, (long)F2 * C, h->lin_w, h->lin_b, h->x.p, D, N, D, F2 * C);
     if (sp && C % 32 == 0) sp_a(l);
@@ -911,7 +917,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
   ln.rows = N; ln.d = D; ln.ta = Ta; ln.dk = dk; ln.eps = 1e-5f; ln.rcos = h->rot_cos; ln.rsin = h->rot_sin;
   ln.rope_rows = c.pos_emb_max_len;
   // split-fp16 modes: every LayerNorm hands its GEMMs a per-row power-of-two scale (gam_row_scale)
-  float* const rs = h->gemm_mode == GAM_GEMM_F16X3 ? h->rsbuf.p : nullptr;
+  float* const rs = h->gemm_mode == GAM_GEMM_F16X3 && h->use_rowscale ? h->rsbuf.p : nullptr;
   ln.rs = rs;
   if (nl > 0) {
     GamLnArgs a = ln;
@@ -924,7 +930,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     // --- FFN 1 (macaron half step) ---
     {
       GamGemmArgs g = gemm_args(h->y.p, D, L.ff1_w1, L.ff1_b1, h->hbuf.p, DFF, N, DFF, D);
-      sp_a(g); g.c_split = sp; g.a_rs = rs;
+      sp_a(g); g.c_split = sp; g.a_rs = rs; g.c_guard = 1;
       if (int r = gemm(h, s, g, GAM_ACT_SILU, GAM_PF_GEMM, &L.s_ff1_w1)) return r;
       GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff1_w2, L.ff1_b2, h->x.p, D, N, D, DFF);
       g2.R = h->x.p; g2.ldr = D; g2.alpha = 0.5f;
@@ -978,7 +984,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       GamConvModArgs cm;
       cm.u = h->ubuf.p; cm.z = h->zbuf.p; cm.dw_w = L.dw_w; cm.dw_b = L.dw_b; cm.n_scale = L.cn_scale; cm.n_shift = L.cn_shift;
       cm.lens = len2; cm.B = B; cm.Ta = Ta; cm.Tv = Tv; cm.d = D; cm.ks = c.conv_kernel_size; cm.eps = 1e-5f;
-      cm.z_split = sp; cm.range_flag = h->range_flag;
+      cm.z_split = sp; cm.range_flag = h->use_range ? h->range_flag : nullptr;
       {
         ProfScope ps(h, s, GAM_PF_CONVMOD, (double)N * D * 3 * 4.0);
         hipError_t e = gam_launch_convmod(cm, c.conv_norm_type == GAM_NORM_LAYER, s);
@@ -996,7 +1002,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       a.split1 = sp;
       if (int r = layernorm(h, s, a, 0)) return r;
       GamGemmArgs g = gemm_args(h->y.p, D, L.ff2_w1, L.ff2_b1, h->hbuf.p, DFF, N, DFF, D);
-      sp_a(g); g.c_split = sp; g.a_rs = rs;
+      sp_a(g); g.c_split = sp; g.a_rs = rs; g.c_guard = 1;
       if (int r = gemm(h, s, g, GAM_ACT_SILU, GAM_PF_GEMM, &L.s_ff2_w1)) return r;
       GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff2_w2, L.ff2_b2, h->x.p, D, N, D, DFF);
       g2.R = h->x.p; g2.ldr = D; g2.alpha = 0.5f;
@@ -1262,6 +1268,14 @@ int gam_op_gemm(gam_handle* h, const float* A, const float* W, const float* bias
                        (_Float16*)h->aplanes.p, an / 4, (const float*)h->op_rs.p, K);
     w16.sp = (_Float16*)h->op_sp.p;
     g.Asp = (const _Float16*)h->aplanes.p;
+  } else if (K % 4 == 0) {   // 128x128 kernel: a row-scaled fp32 copy of A (what the LayerNorm kernels write inside the encoder)
+    const size_t an = (size_t)M * K;
+    if (int r = ensure(h, h->aplanes, an + 64)) return r;
+    hipLaunchKernelGGL(gam_scale_rows_kernel, dim3((int)std::min<size_t>((an / 4 + 255) / 256, 8192)), dim3(256), 0, s, A,
+                       h->aplanes.p, an / 4, (const float*)h->op_rs.p, K);
+    g.A = h->aplanes.p;
+  } else {
+    g.a_rs = nullptr;
   }
   return gemm(h, s, g, act, GAM_PF_GEMM, &w16);
 }

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(512, 4) void gam_convmod_bn_kernel(GamConvModArgs a
     const f32x4 y = (acc[i] + bias) * sc + sh;
     const float v0 = gam_silu(y.x), v1 = gam_silu(y.y), v2 = gam_silu(y.z), v3 = gam_silu(y.w);
     if (t < a.Ta) {
-      if (a.z_split) gam_range_note(a.range_flag, v0, v1, v2, v3);
+      gam_range_note(a.range_flag, v0, v1, v2, v3);   // z feeds the pointwise-conv2 GEMM unscaled
       gam_store4(a.z, (rowbase + t) * (size_t)a.d, c, v0, v1, v2, v3, a.z_split);
     }
   }
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void gam_convmod_ln4_kernel(GamConvModArgs a) 
     if (t < a.Ta) {
       const float v0 = gam_silu((y[i].x - mean[i]) * rstd[i] * gm.x + be.x), v1 = gam_silu((y[i].y - mean[i]) * rstd[i] * gm.y + be.y);
       const float v2 = gam_silu((y[i].z - mean[i]) * rstd[i] * gm.z + be.z), v3 = gam_silu((y[i].w - mean[i]) * rstd[i] * gm.w + be.w);
-      if (a.z_split) gam_range_note(a.range_flag, v0, v1, v2, v3);
+      gam_range_note(a.range_flag, v0, v1, v2, v3);   // z feeds the pointwise-conv2 GEMM unscaled
       gam_store4(a.z, (rowbase + t) * (size_t)a.d, c, v0, v1, v2, v3, a.z_split);
     }
   }

@@ -66,11 +66,14 @@ struct GamGemmArgs {
   int ntiles;           // set by the launcher
   int dbg;              // experiment switches (GAM_SP_DBG), 0 in production
   float wscale_inv;     // 2^-wshift, applied to the accumulator in the epilogue
-  // split-fp16 modes: per-row pre-scale of the A operand (gam_common.h gam_row_scale).  a_rs[m] = 2^-e_m multiplies
-  // row m's accumulators in the epilogue; an sp32 A arrives already scaled by 2^e_m, an fp32 A is scaled while the
-  // 128x128 kernel splits it.  null = none (always null on the exact-fp32 path).
+  // split-fp16 modes: per-row pre-scale of the A operand (gam_common.h gam_row_scale).  The producing kernel stored row m
+  // multiplied by 2^e_m (sp32 or fp32 alike); a_rs[m] = 2^-e_m multiplies row m's accumulators in the epilogue.
+  // null = none (always null on the exact-fp32 path).
   const float* a_rs;
-  int* range_flag;      // c_split outputs carry no row scale: values beyond fp16's range set this flag (may be null)
+  // Range guard: C feeds a split-fp16 GEMM as an UNSCALED operand (FFN hidden, stem activations).  With c_guard set, a
+  // value beyond fp16's range written to C sets *range_flag (gam_common.h gam_range_note); may be null.
+  int* range_flag;
+  int c_guard;
   int prio;             // LDS-DMA GEMM: s_setprio 1 for the later-dispatched half of the waves (GAM_SP_PRIO, A/B switch)
 };
 
@@ -84,7 +87,10 @@ struct GamGemmArgs {
 template <int ACT>
 __device__ __forceinline__ void gam_gemm_epilogue(const GamGemmArgs& g, const f32x16& acc00, const f32x16& acc01,
                                                   const f32x16& acc10, const f32x16& acc11, int m0, int n0, int wm,
-                                                  int wn, int lane, float accscale) {
+                                                  int wn, int lane, float accscale, const float* rs_lds = nullptr) {
+  // rs_lds: the tile's per-row A-operand factors (a_rs[m0 + i]) staged in LDS by the caller, or null (none).  (They were
+  // first loaded into a 16-register array per 32-row slab here: +32 VGPRs, and the pipelined 128x128 kernel dropped
+  // from 3 to 2 waves per SIMD -- a single 5 s clip went from 3.6 to 4.6 ms.)
   const int lcol = lane & 31;
   const int lrow4 = 4 * (lane >> 5);
   if (g.partial != nullptr) {   // split-K slice: raw partial sums, the reduce kernel finishes
@@ -100,20 +106,13 @@ __device__ __forceinline__ void gam_gemm_epilogue(const GamGemmArgs& g, const f3
           const int col = n0 + wn * 64 + tn * 32 + lcol;
           if (col < g.N)
             P[(size_t)row * g.N + col] = (tm == 0 ? (tn == 0 ? acc00[r] : acc01[r]) : (tn == 0 ? acc10[r] : acc11[r])) *
-                                         (accscale * (g.a_rs != nullptr ? g.a_rs[row] : 1.0f));
+                                         (accscale * (rs_lds != nullptr ? rs_lds[row - m0] : 1.0f));
         }
       }
     return;
   }
 #pragma unroll
   for (int tm = 0; tm < 2; ++tm) {
-    float rsv[16];   // row factors of this 32-row slab, loaded together (see gam_gemm_sp.h)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
-      row = row < g.M ? row : g.M - 1;
-      rsv[r] = g.a_rs != nullptr ? g.a_rs[row] : 1.0f;
-    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = m0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + lrow4;
@@ -128,7 +127,7 @@ __device__ __forceinline__ void gam_gemm_epilogue(const GamGemmArgs& g, const f3
           orow = (long)bb * g.out_rpb + tt + g.out_shift;
         }
       }
-      const float rowscale = accscale * rsv[r];
+      const float rowscale = rs_lds != nullptr ? accscale * rs_lds[row - m0] : accscale;
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
         const int col = n0 + wn * 64 + tn * 32 + lcol;
@@ -140,6 +139,7 @@ __device__ __forceinline__ void gam_gemm_epilogue(const GamGemmArgs& g, const f3
         if (masked) v = 0.0f;
         v *= g.alpha;
         if (g.R != nullptr) v += g.R[orow * g.ldr + col];
+        if (g.c_guard) gam_range_note(g.range_flag, v, 0.f, 0.f, 0.f);
         g.C[orow * g.ldc + col] = v;
       }
     }
@@ -373,9 +373,11 @@ __global__ __launch_bounds__(256) void gam_splitk_reduce_kernel(GamGemmArgs g, i
       v[e] = x;
     }
     if (VEC == 4) {
+      if (g.c_guard) gam_range_note(g.range_flag, v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]);
       if (g.c_split) gam_store4(g.C, (size_t)orow * g.ldc, col, v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC], 1);
       else *reinterpret_cast<f32x4*>(g.C + orow * g.ldc + col) = (f32x4){v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]};
     } else {
+      if (g.c_guard) gam_range_note(g.range_flag, v[0], 0.f, 0.f, 0.f);
       gam_store1(g.C, (size_t)orow * g.ldc, col, v[0], g.c_split);
     }
   }

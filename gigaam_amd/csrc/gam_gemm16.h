@@ -69,14 +69,12 @@ __global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : 3)) void gam_ge
   constexpr int AEL = 4;   // elements per A staging item (fp32 A, split while it is staged)
   size_t a_off[AF];
   int a_lds[AF];
-  float a_sc[AF];   // 2^e of the item's row (1 without a row pre-scale): exact, undone in the epilogue by a_rs[row]
 #pragma unroll
   for (int i = 0; i < AF; ++i) {
     const int f = tid + NT * i;
     const int row = f / F4R, c4 = (f % F4R) * AEL;
     int m = m0 + row;
     m = m < g.M ? m : g.M - 1;
-    a_sc[i] = g.a_rs != nullptr ? 1.0f / g.a_rs[m] : 1.0f;
     size_t off;
     if (g.a_mode == 0) off = (size_t)m * (size_t)g.lda;
     else {
@@ -130,8 +128,7 @@ __global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : 3)) void gam_ge
 #pragma unroll
     for (int i = 0; i < AF; ++i) {
       gam_half4 hi, lo;
-      gam_split4(va[i] * a_sc[i], hi, lo);
-      if (g.a_rs == nullptr) gam_range_note(g.range_flag, va[i].x, va[i].y, va[i].z, va[i].w);
+      gam_split4(va[i], hi, lo);
       *reinterpret_cast<gam_half4*>(ah + a_lds[i]) = hi;
       *reinterpret_cast<gam_half4*>(al + a_lds[i]) = lo;
     }
@@ -172,8 +169,7 @@ __global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : 3)) void gam_ge
       if (j < AF) {
         if constexpr (decltype(st)::value) {
           gam_half4 hi, lo;
-          gam_split4(va[j] * a_sc[j], hi, lo);
-          if (g.a_rs == nullptr) gam_range_note(g.range_flag, va[j].x, va[j].y, va[j].z, va[j].w);
+          gam_split4(va[j], hi, lo);
           *reinterpret_cast<gam_half4*>(Ahi + sbuf * Cfg::STAGE + a_lds[j]) = hi;
           *reinterpret_cast<gam_half4*>(Alo + sbuf * Cfg::STAGE + a_lds[j]) = lo;
         }
@@ -245,7 +241,16 @@ __global__ __launch_bounds__(2 * BM, PIPE ? 2 : (BM == 256 ? 4 : 3)) void gam_ge
   }
 #undef GAM_K16
 #undef GAM_MF16
-  gam_gemm_epilogue<ACT>(g, acc00, acc01, acc10, acc11, m0, n0, wm, wn, lane, g.wscale_inv);
+  // the tile's row factors go through LDS (the stages are dead): one global load per row, no register array
+  const float* rs_lds = nullptr;
+  if (g.a_rs != nullptr) {
+    float* rl = reinterpret_cast<float*>(gam_smem16);
+    __syncthreads();                       // every wave is done reading the last k-tile
+    if (tid < BM) { const int m = m0 + tid; rl[tid] = g.a_rs[m < g.M ? m : g.M - 1]; }
+    __syncthreads();
+    rs_lds = rl;
+  }
+  gam_gemm_epilogue<ACT>(g, acc00, acc01, acc10, acc11, m0, n0, wm, wn, lane, g.wscale_inv, rs_lds);
 }
 
 template <int ACT, int BM = 128, bool PIPE = false>

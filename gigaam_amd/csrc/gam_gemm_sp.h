@@ -315,7 +315,7 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
         _Float16* cp = reinterpret_cast<_Float16*>(g.C) + orow * (2 * g.ldc) + (ecol >> 5) * 64 + (ecol & 31);
         gam_half4 hi, lo;
         gam_split4(v, hi, lo);
-        gam_range_note(g.range_flag, v.x, v.y, v.z, v.w);
+        if (g.c_guard) gam_range_note(g.range_flag, v.x, v.y, v.z, v.w);
         *reinterpret_cast<gam_half4*>(cp) = hi;
         *reinterpret_cast<gam_half4*>(cp + 32) = lo;
       } else {
@@ -414,6 +414,14 @@ __global__ __launch_bounds__(256) void gam_to_sp32_kernel(const float* __restric
     *reinterpret_cast<gam_half4*>(p) = h;
     *reinterpret_cast<gam_half4*>(p + 32) = l;
   }
+}
+
+// fp32 [rows, K] -> fp32 copy with row r multiplied by 2^e_r = 1 / rs[r] (the 128x128 kernel's scaled operand)
+__global__ __launch_bounds__(256) void gam_scale_rows_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n4,
+                                                             const float* __restrict__ rs, int K) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+    reinterpret_cast<f32x4*>(y)[i] = reinterpret_cast<const f32x4*>(x)[i] * (1.0f / rs[(i * 4) / (size_t)K]);
 }
 
 // rs[row] = 2^-e with max|row| 2^e in [2^7, 2^8): one wave per row of an fp32 [rows, K] matrix (row pitch lda)

@@ -23,8 +23,8 @@ struct GamLnArgs {
   int split1, split2;   // write out1 / out2 in the sp32 GEMM-operand layout (gam_common.h)
   // Per-row pre-scale of the GEMM operand this kernel produces (gam_row_scale): rs[row] = 2^-e is what the
   // consuming GEMM multiplies its accumulators by.  MODE 0: out1; MODE 1: out1 AND out2 (one scale for the
-  // plain and the rotated copy); MODE 2: out2.  An sp32 output is stored scaled; an fp32 output is stored as
-  // is (the 128x128 GEMM applies the scale while it splits).  null = no scaling.
+  // plain and the rotated copy); MODE 2: out2 (out1 is the residual stream, never scaled).  The operand is
+  // stored multiplied by 2^e in either format (sp32 or fp32: these outputs feed GEMMs only).  null = no scaling.
   float* rs;
   int rope_rows;        // rows of rcos / rsin (pos_emb_max_len): the stride-padding rows of a row block clamp to it
 };
@@ -87,8 +87,8 @@ __global__ __launch_bounds__(256) void gam_layernorm_kernel(GamLnArgs a) {
     float s_, inv_;
     gam_row_scale(gam_ln_rowmax(v, a.d, lane), s_, inv_);
     if (live && lane == 0) a.rs[row] = inv_;
-    if (a.split1) sc1 = s_;
-    if (a.split2) sc2 = s_;
+    sc1 = s_;
+    sc2 = s_;
   }
   if (live) {
 #pragma unroll
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void gam_layernorm_kernel(GamLnArgs a) {
       float s_, inv_;
       gam_row_scale(gam_ln_rowmax(v, a.d, lane), s_, inv_);
       if (live && lane == 0) a.rs[row] = inv_;
-      if (a.split2) sc2 = s_;
+      sc2 = s_;
     }
     if (live) {
 #pragma unroll

@@ -29,9 +29,15 @@ def collate(segments: Sequence[Tensor], out: Tensor = None) -> Tuple[Tensor, Ten
         batch = torch.zeros((b, lmax), dtype=segments[0].dtype if b else torch.float32)
     else:
         batch = out[: b * lmax].view(b, lmax)
-        batch.zero_()
+    # plain single-threaded memset / memcpy through numpy views: a torch op on a 20 MB CPU tensor fans out over every
+    # OpenMP thread of the host, and on a box with a CPU quota those spinning threads get the whole process throttled
+    # for tens of milliseconds -- seen as 50 ms holes in the middle of a batch's kernel launches (profiles/r02_config5_*)
+    hb = batch.numpy()
+    if out is not None:
+        hb.fill(0)
     for j, c in enumerate(segments):
-        batch[j, : c.shape[-1]] = c.reshape(-1)
+        src = c.reshape(-1)
+        hb[j, : src.shape[0]] = src.numpy() if src.device.type == "cpu" and not src.requires_grad else src.detach().cpu().numpy()
     return batch, lens
 
 
