@@ -170,15 +170,11 @@ class HipComm:
         return a_index, a_counts, a_ids, a_frames
 
     def close(self) -> None:
+        """ncclCommDestroy.  Explicit only: a communicator still alive at interpreter exit is left to the OS (destroying
+        it from ``__del__`` during shutdown would run after torch has torn its HIP context down)."""
         if getattr(self, "_c", None):
             self.lib.gam_comm_destroy(self._c)
             self._c = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
 
 
 def torch_gather(index: Optional[Tensor], counts: Tensor, ids: Tensor, frames: Tensor):
