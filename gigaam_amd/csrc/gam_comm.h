@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 #include "../../include/gigaam_hip.h"
@@ -30,20 +31,23 @@ struct Api {
   std::string err;
 };
 
-static inline Api* api() {
+static inline void load(Api& a);
+static inline Api* api() {   // resolved once per process (thread-safe)
   static Api a;
-  static bool tried = false;
-  if (tried) return &a;
-  tried = true;
+  static std::once_flag once;
+  std::call_once(once, [] { load(a); });
+  return &a;
+}
+static inline void load(Api& a) {
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names) {
     a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
     if (a.lib) break;
   }
-  if (!a.lib) { a.err = std::string("cannot load librccl: ") + dlerror(); return &a; }
+  if (!a.lib) { a.err = std::string("cannot load librccl: ") + dlerror(); return; }
 #define GAM_RCCL_SYM(field, name)                                         \
   a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, name));     \
-  if (!a.field) { a.err = std::string("librccl lacks ") + name; a.lib = nullptr; return &a; }
+  if (!a.field) { a.err = std::string("librccl lacks ") + name; a.lib = nullptr; return; }
   GAM_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
   GAM_RCCL_SYM(CommInitRank, "ncclCommInitRank");
   GAM_RCCL_SYM(CommDestroy, "ncclCommDestroy");
@@ -52,7 +56,6 @@ static inline Api* api() {
   GAM_RCCL_SYM(GroupEnd, "ncclGroupEnd");
   GAM_RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef GAM_RCCL_SYM
-  return &a;
 }
 }  // namespace gam_rccl
 

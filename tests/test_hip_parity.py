@@ -491,3 +491,62 @@ def test_fp16_encoder_contract(tmp_path):
     e32, n32 = m32.forward(w16.float(), l16)      # the same fp16-rounded samples through the fp32 contract
     assert torch.equal(n16, n32) and torch.equal(e16, e32.half())
     assert isinstance(str(m16.transcribe(wpath)), str)
+
+
+def test_word_timestamps_match_oracle_derived_words(tmp_path):
+    """transcribe(word_timestamps=True).words on the GPU == frames_to_words over the ORACLE's ids / frames (the function
+    itself is pinned to the reference's by tests/test_host_golden.py): texts equal, start / end equal to the float."""
+    import wave
+    import gigaam_amd
+    from gigaam_amd import synth
+    from gigaam_amd.decoding import Tokenizer
+    from gigaam_amd.timestamps_utils import compute_frame_shift, frames_to_words
+    ck = synth.make_checkpoint("v2_ctc", seed=1, n_layers=2)
+    model = gigaam_amd.model_from_checkpoint(ck, "cuda:0")
+    wav, _ = synth.synth_audio(1, 6.0, seed=21)
+    pcm = (wav[0].numpy() * 32768.0).round().clip(-32768, 32767).astype(np.int16)
+    wpath = str(tmp_path / "clip.wav")
+    with wave.open(wpath, "wb") as wf:
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000); wf.writeframes(pcm.tobytes())
+    res = model.transcribe(wpath, word_timestamps=True)
+    x = torch.from_numpy(pcm.astype(np.float32) / 32768.0)[None]
+    with torch.no_grad():
+        dec, _, elen_o = O.transcribe_ids(ck, x, torch.tensor([x.shape[1]]))
+    ids, frames = dec[0]
+    want = frames_to_words(Tokenizer(synth.CHAR_VOCAB), ids, frames, compute_frame_shift(x.shape[1], int(elen_o[0])))
+    assert len(want) >= 3
+    assert [(w.text, w.start, w.end) for w in res.words] == [(w.text, w.start, w.end) for w in want]
+    # longform: the same words, offset by the segment start and rounded to 3 decimals (model.py:246-250)
+    lf = model.transcribe_longform(wpath, word_timestamps=True, speech_regions=[(0.0, 6.0)], min_duration=1.0, max_duration=8.0)
+    assert [(w.text, w.start, w.end) for w in lf.segments[0].words] == [(w.text, round(w.start, 3), round(w.end, 3)) for w in want]
+
+
+def test_batch_feeder_matches_reference_collate():
+    """The pinned, double-buffered feeder hands the GPU exactly the reference's collate layout
+    (gigaam/utils.py:371-380; fixture tests/golden/host_logic.json), batch after batch, on the side stream."""
+    import hashlib
+    import json
+    import os
+    from common import ROOT
+    from gigaam_amd.feeder import BatchFeeder
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "host_logic.json"), encoding="utf-8"))["collate"]
+
+    def seeded_audio(n, seed):
+        g = np.random.Generator(np.random.PCG64(seed))
+        return torch.from_numpy(g.standard_normal(n, dtype=np.float32) * np.float32(0.1))
+
+    for c in fx:
+        wavs = [seeded_audio(n, 1000 * c["seed"] + j) for j, n in enumerate(c["lens"])]
+        got = list(BatchFeeder(wavs, len(wavs), torch.device("cuda:0")))
+        assert len(got) == 1
+        wav, lens = got[0]
+        torch.cuda.synchronize()
+        assert wav.is_cuda and list(wav.shape) == c["shape"] and lens.cpu().tolist() == c["lengths"]
+        assert hashlib.sha256(wav.cpu().contiguous().numpy().tobytes()).hexdigest()[:16] == c["batch_sha"]
+    # several batches, ragged tail: concatenation of the batches == the segments, in order
+    segs = [seeded_audio(100 + 37 * i, i) for i in range(11)]
+    out = []
+    for wav, lens in BatchFeeder(segs, 4, torch.device("cuda:0")):
+        torch.cuda.synchronize()
+        out += [wav[j, : int(n)].cpu() for j, n in enumerate(lens.cpu().tolist())]
+    assert len(out) == 11 and all(torch.equal(a, b) for a, b in zip(out, segs))
