@@ -58,6 +58,35 @@ def test_frontend_against_torchaudio_fixture(case):
     assert e_strong < TOL_FEAT and e_weak < TOL_FEAT_WEAK, (e_strong, e_weak)
 
 
+@pytest.mark.parametrize("model", ["v2_ctc", "v3_ctc"])
+def test_frontend_against_transformers_audio_utils(model):
+    """A third independent statement of the same published algorithm: Hugging Face's ``transformers.audio_utils``
+    (periodic Hann, reflect padding / center=False, power spectrogram, HTK filterbank with norm=None, log with a floor) --
+    the implementation HF's feature extractors use, evaluated in fp64.  Not the reference either (row a1 stays
+    "parity unpinned" until tests/golden/make_frontend_golden.py runs next to torchaudio), but the restatement, scipy.fft
+    and this library agree on frame counts, the filterbank (3e-8) and the log-mel values (<= 1e-4 / 4e-4)."""
+    audio_utils = pytest.importorskip("transformers.audio_utils")
+    from gigaam_amd import synth
+    cfg = synth.model_cfg(model)["preprocessor"]
+    n_fft, win, hop = cfg.get("n_fft", 400), cfg.get("win_length", 400), cfg.get("hop_length", 160)
+    center = cfg.get("center", True)
+    wav, wlen = synth.synth_audio(1, 2.0, seed=3)
+    fb = audio_utils.mel_filter_bank(num_frequency_bins=n_fft // 2 + 1, num_mel_filters=64, min_frequency=0.0, max_frequency=8000.0,
+                                     sampling_rate=16000, norm=None, mel_scale="htk")
+    spec = audio_utils.spectrogram(wav[0].numpy().astype(np.float64), audio_utils.window_function(win, "hann", periodic=True),
+                                   frame_length=win, hop_length=hop, fft_length=n_fft, power=2.0, center=center, pad_mode="reflect",
+                                   onesided=True, mel_filters=fb, mel_floor=1e-9, log_mel="log")
+    win_t = torch.from_numpy(synth.hann_window_periodic(win))
+    fb_t = torch.from_numpy(synth.mel_filterbank_htk(n_fft // 2 + 1, 64, 16000))
+    assert float(np.abs(fb - fb_t.numpy()).max()) < 1e-6
+    feat, flen = O.log_mel(wav, wlen, cfg, win_t, fb_t)
+    assert spec.shape == tuple(feat.shape[1:]) and int(flen[0]) == spec.shape[1]
+    f = feat[0].numpy().astype(np.float64)
+    strong = f >= f.max(axis=0, keepdims=True) - 60.0 * 0.2302585
+    d = np.abs(spec - f)
+    assert d[strong].max() < 3e-4 and d.max() < 2e-3, (d[strong].max(), d.max())
+
+
 def test_emotion_head_oracle_matches_reference_golden():
     """GigaAMEmo (model.py:272-293): tests/golden/emo_l2.npz holds what the reference's own get_probs /
     forward_for_export bodies returned (make_golden.py runs them unbound on the reference encoder)."""
