@@ -1163,14 +1163,15 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
     int C = (256 - 16) / (8 * nu8);   // one workgroup per CU with a few CUs to spare (members spin on each other)
     C = C > 8 ? 8 : C;
     if (h->rnnt_cluster >= 0) C = h->rnnt_cluster < C ? h->rnnt_cluster : C;
-    if (C >= 1 && JH % 4 == 0 && a.H % 4 == 0) {
+    if (C >= 1 && JH % 16 == 0 && a.H % 4 == 0) {   // (JH % 16: MFMA k-steps and the LDS-DMA window)
       GamRnntClusterArgs ca;
       ca.a = a; ca.whh_q = h->lstm_whh_q; ca.wpred_q = h->jn_pred_q; ca.C = C;
       const int nI = gam_cdiv(a.H, C), need = gam_cdiv(4 * nI, 256);
       const int nr = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 3 ? 3 : (need <= 5 ? 5 : 8)));
       const int nV = gam_cdiv(gam_cdiv(a.V, C), 16) * 16;
       ca.wout_slice_in_lds = (size_t)nV * (JH + 4) * 4 + gam_rnnt_cluster_smem(a.H, JH, a.V, C, nr, 0) <= 96 * 1024 ? 1 : 0;
-      const size_t sm = gam_rnnt_cluster_smem(a.H, JH, a.V, C, nr, ca.wout_slice_in_lds);
+      ca.wpred_slice_in_lds = gam_rnnt_cluster_smem(a.H, JH, a.V, C, nr, ca.wout_slice_in_lds, 1) <= 150 * 1024 ? 1 : 0;
+      const size_t sm = gam_rnnt_cluster_smem(a.H, JH, a.V, C, nr, ca.wout_slice_in_lds, ca.wpred_slice_in_lds);
       const size_t xg = gam_rnnt_cluster_xgranules(a.H, JH, C) * (size_t)B;
       if (sm <= 160 * 1024 && need <= 8) {
         if (int r = ensure(h, h->rnnt_x, xg * 2 + 64)) return r;   // (floats: 2 per granule) + status word
@@ -1185,10 +1186,18 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
     hipLaunchKernelGGL(gam_rnnt_cluster_kernel<NRV>, grid, dim3(256), sm, s, ca);                                          \
   }
         static std::atomic<unsigned long long> at1r{0};
-        if (nr == 1 && a.H == 320) {   // W_hh rows register-resident (gam_decode_cluster.h RESQ)
+        if (nr == 1 && a.H == 320 && JH == 320) {   // W_hh rows register-resident (gam_decode_cluster.h RESQ)
           HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<1, 80>), 160 * 1024, at1r));
           hipLaunchKernelGGL((gam_rnnt_cluster_kernel<1, 80>), grid, dim3(256), sm, s, ca);
           HIPCHK(h, hipGetLastError());
+          if (GAM_RC_TIMING && getenv("GAM_RNNT_TIMING")) {
+            int st[16];
+            HIPCHK(h, hipStreamSynchronize(s));
+            HIPCHK(h, hipMemcpy(st, ca.status, sizeof st, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[gam] rnnt cluster C=%d (resident) utt0: rounds %d; us: gates %.0f xH %.0f pred %.0f xP %.0f z %.0f joint %.0f xA %.0f comb %.0f ctrl %.0f\n", C,
+                    st[T_ROUNDS], st[T_GATES] / 100.0, st[T_XH] / 100.0, st[T_PRED] / 100.0, st[T_XP] / 100.0, st[T_Z] / 100.0, st[T_JOINT] / 100.0,
+                    st[T_XA] / 100.0, st[T_COMB] / 100.0, st[T_CTRL] / 100.0);
+          }
           return 0;
         }
         switch (nr) {
@@ -1200,6 +1209,14 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
         }
 #undef GAM_RC_LAUNCH
         HIPCHK(h, hipGetLastError());
+        if (GAM_RC_TIMING && getenv("GAM_RNNT_TIMING")) {
+          int st[16];
+          HIPCHK(h, hipStreamSynchronize(s));
+          HIPCHK(h, hipMemcpy(st, ca.status, sizeof st, hipMemcpyDeviceToHost));
+          fprintf(stderr, "[gam] rnnt cluster C=%d utt0: rounds %d; us: gates %.0f xH %.0f pred %.0f xP %.0f z %.0f joint %.0f xA %.0f comb %.0f ctrl %.0f\n", C,
+                  st[T_ROUNDS], st[T_GATES] / 100.0, st[T_XH] / 100.0, st[T_PRED] / 100.0, st[T_XP] / 100.0, st[T_Z] / 100.0, st[T_JOINT] / 100.0,
+                  st[T_XA] / 100.0, st[T_COMB] / 100.0, st[T_CTRL] / 100.0);
+        }
         return 0;
       }
     }

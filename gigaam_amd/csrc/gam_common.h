@@ -7,6 +7,7 @@
 #define GAM_WAVE 64
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int gam_cdiv(long a, long b) { return (int)((a + b - 1) / b); }

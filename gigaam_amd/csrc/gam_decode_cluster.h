@@ -35,9 +35,21 @@ struct GamRnntClusterArgs {
   int* status;               // != 0: a hand-off timed out somewhere in this launch
   int C;                     // workgroups per utterance
   int wout_slice_in_lds;     // this member's class slice of W_out is cached in LDS
+  int wpred_slice_in_lds;    // this member's rows of W_pred are cached in LDS ([H/4][nP][4]): the step's pp no longer waits on L2
 };
 
 #define GAM_RC_WIN 16
+// -DGAM_RC_TIMING=1: per-phase wall-clock totals (10 ns ticks) of utterance 0 / member 0 go to status[1..10] and
+// gam_rnnt_greedy prints them (GAM_RNNT_TIMING=1); production builds carry none of it.
+#ifndef GAM_RC_TIMING
+#define GAM_RC_TIMING 0
+#endif
+enum { T_GATES = 1, T_XH, T_PRED, T_XP, T_Z, T_JOINT, T_XA, T_COMB, T_CTRL, T_ROUNDS };
+#if GAM_RC_TIMING
+#define GAM_RC_MARK(id) { const long long now_ = wall_clock64(); tacc[id] += now_ - tlast; tlast = now_; }
+#else
+#define GAM_RC_MARK(id)
+#endif
 #define GAM_RC_TIMEOUT_TICKS 100000000LL   // wall_clock64 ticks (100 MHz): 1 s
 
 __device__ __forceinline__ void gam_rc_put(unsigned long long* p, float v, unsigned tag) {
@@ -62,11 +74,36 @@ __device__ __forceinline__ bool gam_rc_get(const unsigned long long* p, unsigned
   }
 }
 
-static inline size_t gam_rnnt_cluster_smem(int H, int JH, int V, int C, int nr, int wout_slice_in_lds) {
+// poll granule p0 and (when ``two``) p1 with both loads in flight: one L2 round trip instead of two for the threads
+// that own two granules of a 320-wide exchange
+__device__ __forceinline__ bool gam_rc_get2(const unsigned long long* p0, const unsigned long long* p1, bool two, unsigned tag,
+                                            float& v0, float& v1, int* status) {
+  long long t_end = 0;
+  bool d0 = false, d1 = !two;
+  for (unsigned spin = 0;; ++spin) {
+    const unsigned long long g0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long g1 = __hip_atomic_load(two ? p1 : p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!d0 && (unsigned)(g0 >> 32) == tag) { v0 = __uint_as_float((unsigned)g0); d0 = true; }
+    if (!d1 && (unsigned)(g1 >> 32) == tag) { v1 = __uint_as_float((unsigned)g1); d1 = true; }
+    if (d0 && d1) return true;
+    if ((spin & 255u) == 255u) {
+      const long long now = wall_clock64();
+      if (t_end == 0) t_end = now + GAM_RC_TIMEOUT_TICKS;
+      if (now > t_end || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        atomicOr(status, 1);
+        return false;
+      }
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+
+static inline size_t gam_rnnt_cluster_smem(int H, int JH, int V, int C, int nr, int wout_slice_in_lds, int wpred_slice_in_lds = 0) {
   const int nV = ((V + C - 1) / C + 15) / 16 * 16;
   size_t f = (size_t)4 * H + 256 * (size_t)nr + JH + 1024 + (size_t)GAM_RC_WIN * (JH + 4) + (size_t)GAM_RC_WIN * (nV + 1) + 64 +
-             (size_t)C * 48 + 16;
+             (size_t)C * 48 + 16 + (size_t)GAM_RC_WIN * JH;
   if (wout_slice_in_lds) f += (size_t)nV * (JH + 4);
+  if (wpred_slice_in_lds) f += (size_t)H * ((JH + C - 1) / C);
   return sizeof(float) * f;
 }
 __host__ __device__ static inline size_t gam_rnnt_cluster_xgranules(int H, int JH, int C) {
@@ -86,7 +123,8 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
   const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
   const int b = (slot / C) * 8 + xcd, cm = slot % C;
   if (b >= a.B) return;   // (whole clusters drop out together)
-  const int H = a.H, JH = a.JH, V = a.V, blank = a.V - 1;
+  // (the resident kernel is launched only for H == JH == 4 RESQ: compile-time sizes free ~100 scalar registers)
+  const int H = RESQ > 0 ? 4 * RESQ : a.H, JH = RESQ > 0 ? 4 * RESQ : a.JH, V = a.V, blank = a.V - 1;
   const int nI = (H + C - 1) / C, i0 = cm * nI, i1 = i0 + nI < H ? i0 + nI : H;        // my hidden units
   const int nP = (JH + C - 1) / C, r0 = cm * nP, r1 = r0 + nP < JH ? r0 + nP : JH;     // my rows of W_pred
   const int nV = ((V + C - 1) / C + 15) / 16 * 16, v0 = cm * nV, v1 = v0 + nV < V ? v0 + nV : V;   // my classes
@@ -105,7 +143,9 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
   float* lse_s = reinterpret_cast<float*>(lab_s + GAM_RC_WIN);   // [WIN]
   int* dead_s = reinterpret_cast<int*>(lse_s + GAM_RC_WIN);      // [1] (+ padding to 64)
   float* apart = lse_s + GAM_RC_WIN + 32;                        // [C][WIN][3]  (max, argmax bits, sum-exp)
-  float* wout_l = g.wout_slice_in_lds ? apart + C * 48 : nullptr;   // [nV][WLD] (every segment above is a multiple of 16 bytes)
+  float* zenc = apart + C * 48;                                  // [WIN][JH] encoder-projection rows of the window (LDS-DMA target)
+  float* wout_l = g.wout_slice_in_lds ? zenc + GAM_RC_WIN * JH : nullptr;   // [nV][WLD] (every segment above is a multiple of 16 bytes)
+  float* wpl = g.wpred_slice_in_lds ? zenc + GAM_RC_WIN * JH + (g.wout_slice_in_lds ? nV * WLD : 0) : nullptr;   // [H/4][nP][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg4 = lane >> 4;
   int len = a.enc_len[b];
@@ -119,6 +159,12 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
   if (tid == 0) dead_s[0] = 0;
   if (wout_l != nullptr)
     for (int i = tid; i < (v1 > v0 ? v1 - v0 : 0) * JH; i += 256) wout_l[(i / JH) * WLD + (i % JH)] = a.wout[(size_t)v0 * JH + i];
+  if (wpl != nullptr)
+    for (int i = tid; i < (H / 4) * nP; i += 256) {
+      const int q = i / nP, rr = i - q * nP;
+      const int r = r0 + rr < JH ? r0 + rr : JH - 1;
+      *reinterpret_cast<f32x4*>(wpl + (size_t)i * 4) = *reinterpret_cast<const f32x4*>(g.wpred_q + ((size_t)q * JH + r) * 4);
+    }
   __syncthreads();
 
   // my gate-row slots: slot s = tid + 256 j -> gate s / nI, unit i0 + s % nI
@@ -139,7 +185,25 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
     for (int q = 0; q < RESQ; ++q) wres[q] = *reinterpret_cast<const f32x4*>(g.whh_q + ((size_t)q * 4 * H + grow[0]) * 4);
   }
 
+  // encoder-projection rows of the 16-frame window starting at frame tw, straight into LDS (global_load_lds_dwordx4:
+  // a wave moves 64 x 16 bytes to 1 KiB of zenc, no registers held): in flight while the round that decided tw
+  // finishes and the next predictor step runs; JH % 16 == 0 (launcher) makes the window a whole number of wave loads
+  auto fetch_window = [&](int tw) {
+    const int Wn = len - tw < GAM_RC_WIN ? len - tw : GAM_RC_WIN;
+    for (int c = wave; c < GAM_RC_WIN * JQ / 64; c += 4) {
+      const int idx = c * 64 + lane;
+      const int f = idx / JQ, q = idx - f * JQ;
+      int tt = tw + (f < Wn ? f : Wn - 1);
+      tt = tt < 0 ? 0 : (tt < a.Tp ? tt : a.Tp - 1);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.encp + ((size_t)b * a.Tp + tt) * JH + 4 * q),
+                                       (__attribute__((address_space(3))) void*)(zenc + c * 256), 16, 0, 0);
+    }
+  };
+  fetch_window(0);
   int label = V;       // gate_tab row V: zero embedding (predict(None, None), decoder.py:97-100)
+  float tabv[NR];      // gate_tab[label] of my rows: fetched as soon as the label is known (end of the round that emitted it)
+#pragma unroll
+  for (int j = 0; j < NR; ++j) tabv[j] = a.gate_tab[(size_t)label * 4 * H + grow[j]];
   int n_out = 0, n_dump = 0;
   int t = 0, sym = 0;
   bool need_pred = true;
@@ -147,22 +211,29 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
   int par_h = 0, par_p = 0, par_a = 0;
   bool dead = false;
 
+#if GAM_RC_TIMING
+  long long tacc[12] = {0}, tlast = wall_clock64();
+#endif
   while (t < len && !dead) {
+#if GAM_RC_TIMING
+    tacc[T_ROUNDS] += 1;
+#endif
     if (need_pred) {
       // ---- LSTM gates of my units: tab[label] + W_hh.h, k ascending (same fmaf chain as the 1-workgroup kernel)
       {
         float acc[NR];
 #pragma unroll
-        for (int j = 0; j < NR; ++j) acc[j] = a.gate_tab[(size_t)label * 4 * H + grow[j]];
+        for (int j = 0; j < NR; ++j) acc[j] = tabv[j];
         if constexpr (RESQ > 0) {
+          // four partial sums (k mod 4) as two packed-fp32 chains: 2 x RESQ v_pk_fma_f32 instead of 4 x RESQ dependent fmas
+          f32x2 pa = (f32x2){acc[0], 0.f}, pb = (f32x2){0.f, 0.f};
 #pragma unroll
           for (int q = 0; q < RESQ; ++q) {
             const f32x4 hv = *reinterpret_cast<const f32x4*>(h_s + 4 * q);
-            acc[0] = fmaf(wres[q].x, hv.x, acc[0]);
-            acc[0] = fmaf(wres[q].y, hv.y, acc[0]);
-            acc[0] = fmaf(wres[q].z, hv.z, acc[0]);
-            acc[0] = fmaf(wres[q].w, hv.w, acc[0]);
+            pa = __builtin_elementwise_fma((f32x2){wres[q].x, wres[q].y}, (f32x2){hv.x, hv.y}, pa);
+            pb = __builtin_elementwise_fma((f32x2){wres[q].z, wres[q].w}, (f32x2){hv.z, hv.w}, pb);
           }
+          acc[0] = (pa.x + pa.y) + (pb.x + pb.y);
         } else {
         // float4 loads in flight per row slot: the step is L2-LATENCY bound (each batch of loads is one round trip),
         // so as many as the registers hold -- ~160 VGPRs of weights per thread
@@ -195,6 +266,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
           if (gok[j]) gates[tid + 256 * j] = acc[j];
       }
       __syncthreads();
+    GAM_RC_MARK(T_GATES);
       ++xc;
       for (int ii = tid; i0 + ii < i1; ii += 256) {   // cell update of my units (gate order i, f, g, o)
         const float ig = gam_sigmoid_exact(gates[ii]), fg = gam_sigmoid_exact(gates[nI + ii]);
@@ -206,14 +278,17 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
         else hn_s[i0 + ii] = hn;
       }
       if (C > 1) {
-        for (int i = tid; i < H; i += 256) {
-          float v;
-          if (!gam_rc_get(xh + par_h * H + i, xc, v, g.status)) { dead_s[0] = 1; v = 0.f; }
-          hn_s[i] = v;
+        for (int i = tid; i < H; i += 512) {
+          float va = 0.f, vb = 0.f;
+          const bool two = i + 256 < H;
+          if (!gam_rc_get2(xh + par_h * H + i, xh + par_h * H + i + 256, two, xc, va, vb, g.status)) { dead_s[0] = 1; va = vb = 0.f; }
+          hn_s[i] = va;
+          if (two) hn_s[i + 256] = vb;
         }
         par_h ^= 1;
       }
       __syncthreads();
+    GAM_RC_MARK(T_XH);
       if (dead_s[0]) { dead = true; break; }
       // ---- my rows of W_pred.h' + b_pred
       {
@@ -224,7 +299,11 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
             for (int q0 = 0; q0 < HQ; q0 += 16) {
               f32x4 w[16];
 #pragma unroll
-              for (int u = 0; u < 16; ++u) w[u] = *reinterpret_cast<const f32x4*>(g.wpred_q + ((size_t)(q0 + u < HQ ? q0 + u : HQ - 1) * JH + r) * 4);
+              for (int u = 0; u < 16; ++u) {
+                const int q = q0 + u < HQ ? q0 + u : HQ - 1;
+                w[u] = wpl != nullptr ? *reinterpret_cast<const f32x4*>(wpl + ((size_t)q * nP + rr) * 4)
+                                      : *reinterpret_cast<const f32x4*>(g.wpred_q + ((size_t)q * JH + r) * 4);
+              }
 #pragma unroll
               for (int u = 0; u < 16; ++u)
                 if (q0 + u < HQ) {
@@ -243,7 +322,11 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
             for (int q0 = qa; q0 < qb; q0 += 16) {
               f32x4 w[16];
 #pragma unroll
-              for (int u = 0; u < 16; ++u) w[u] = *reinterpret_cast<const f32x4*>(g.wpred_q + ((size_t)(q0 + u < qb ? q0 + u : qb - 1) * JH + r) * 4);
+              for (int u = 0; u < 16; ++u) {
+                const int q = q0 + u < qb ? q0 + u : qb - 1;
+                w[u] = wpl != nullptr ? *reinterpret_cast<const f32x4*>(wpl + ((size_t)q * nP + rr) * 4)
+                                      : *reinterpret_cast<const f32x4*>(g.wpred_q + ((size_t)q * JH + r) * 4);
+              }
 #pragma unroll
               for (int u = 0; u < 16; ++u)
                 if (q0 + u < qb) {
@@ -256,6 +339,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
         }
       }
       __syncthreads();
+    GAM_RC_MARK(T_PRED);
       ++xc;
       for (int rr = tid; r0 + rr < r1; rr += 256) {
         float v = red[rr];
@@ -264,49 +348,42 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
         else pp[r0 + rr] = v;
       }
       if (C > 1) {
-        for (int i = tid; i < JH; i += 256) {
-          float v;
-          if (!gam_rc_get(xp + par_p * JH + i, xc, v, g.status)) { dead_s[0] = 1; v = 0.f; }
-          pp[i] = v;
+        for (int i = tid; i < JH; i += 512) {
+          float va = 0.f, vb = 0.f;
+          const bool two = i + 256 < JH;
+          if (!gam_rc_get2(xp + par_p * JH + i, xp + par_p * JH + i + 256, two, xc, va, vb, g.status)) { dead_s[0] = 1; va = vb = 0.f; }
+          pp[i] = va;
+          if (two) pp[i + 256] = vb;
         }
         par_p ^= 1;
       }
       need_pred = false;
       __syncthreads();
+    GAM_RC_MARK(T_XP);
       if (dead_s[0]) { dead = true; break; }
     }
 
     // ---- joint of frames t .. t+W-1 with the current predictor state: z = relu(enc + pred) (all JH, every member)
     const int W = len - t < GAM_RC_WIN ? len - t : GAM_RC_WIN;
-    for (int i0z = 0; i0z < GAM_RC_WIN * JQ; i0z += 256 * 4) {
-      f32x4 ze[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        int idx = i0z + tid + 256 * u;
-        idx = idx < GAM_RC_WIN * JQ ? idx : GAM_RC_WIN * JQ - 1;
-        const int f = idx / JQ, q = idx - f * JQ;
-        const int tt = t + (f < W ? f : W - 1);
-        ze[u] = *reinterpret_cast<const f32x4*>(a.encp + ((size_t)b * a.Tp + tt) * JH + 4 * q);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int idx = i0z + tid + 256 * u;
-        if (idx < GAM_RC_WIN * JQ) {
-          const int f = idx / JQ, q = idx - f * JQ;
-          const f32x4 pv = *reinterpret_cast<const f32x4*>(pp + 4 * q);
-          *reinterpret_cast<f32x4*>(zw + f * ZLD + 4 * q) =
-              (f32x4){fmaxf(ze[u].x + pv.x, 0.f), fmaxf(ze[u].y + pv.y, 0.f), fmaxf(ze[u].z + pv.z, 0.f), fmaxf(ze[u].w + pv.w, 0.f)};
-        }
-      }
+    // (the window's encoder-projection rows were fetched when t was decided, at the end of the previous round)
+    __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): my wave's LDS-DMA loads have landed ...
+    __syncthreads();                      // ... and so have everyone else's
+    for (int idx = tid; idx < GAM_RC_WIN * JQ; idx += 256) {
+      const int f = idx / JQ, q = idx - f * JQ;
+      const f32x4 ev = *reinterpret_cast<const f32x4*>(zenc + 4 * idx);
+      const f32x4 pv = *reinterpret_cast<const f32x4*>(pp + 4 * q);
+      *reinterpret_cast<f32x4*>(zw + f * ZLD + 4 * q) =
+          (f32x4){fmaxf(ev.x + pv.x, 0.f), fmaxf(ev.y + pv.y, 0.f), fmaxf(ev.z + pv.z, 0.f), fmaxf(ev.w + pv.w, 0.f)};
     }
     __syncthreads();
+    GAM_RC_MARK(T_Z);
     // logits[f][v] = bout[v] + sum_k z[f][k] wout[v][k] for my classes: one 16x16 MFMA tile per 16 classes
     for (int nt = wave; v0 + nt * 16 < v1; nt += 4) {
       const int v = v0 + nt * 16 + li;
       const int vc = v < V ? v : V - 1;
       const float* wr = (wout_l != nullptr ? wout_l + (size_t)(vc - v0) * WLD : a.wout + (size_t)vc * JH) + 4 * lg4;
       const float* zr = zw + li * ZLD + 4 * lg4;
-      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc, acc2 = acc, acc3 = acc;   // (k mod 4 chains: MFMA latency, not rate, bounds one tile)
       // all of the tile's W_out reads in flight at once (JH / 16 x 16 bytes per lane): with the slice streamed from L2
       // (SentencePiece vocabularies) every batch of loads is one L2 round trip, and a wave runs several tiles
       constexpr int MAXU = GAM_RNNT_MAXH / 16, UB = RESQ > 0 ? 10 : 32;   // (register-resident W_hh leaves room for 10 at a time)
@@ -321,12 +398,13 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
           if (16 * (u0 + u) + 16 <= JH) {
             const float4 zf = *reinterpret_cast<const float4*>(zr + 16 * (u0 + u));
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.x, wf[u].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf[u].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf[u].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf[u].w, acc, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf[u].y, acc1, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf[u].z, acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf[u].w, acc3, 0, 0, 0);
           }
         }
       }
+      acc = (acc + acc1) + (acc2 + acc3);
       if (v < v1) {   // C/D: col = lane&15 = class, row = 4*(lane>>4) + r = frame
         const float bo = a.bout[v];
 #pragma unroll
@@ -334,48 +412,59 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       }
     }
     __syncthreads();
-    // per-frame (max, first argmax, sum-exp) over my classes: wave w takes frames w, w+4, ...
+    GAM_RC_MARK(T_JOINT);
+    // per-frame (max, first argmax, sum-exp) over my classes: 16 lanes per frame, wave w takes frames 4w .. 4w+3
     ++xc;
-    for (int f = wave; f < GAM_RC_WIN; f += 4) {
+    const int NG = a.dump != nullptr ? 3 : 2;   // (the sum-exp is only exchanged when log-probs are dumped)
+    {
+      const int f = 4 * wave + lg4;
       const float* lr = lgw + f * LLD;
       float best = -INFINITY;
       int bi = 0x7fffffff;
       if (f < W)
-        for (int vl = lane; v0 + vl < v1; vl += 64) {
+        for (int vl = li; v0 + vl < v1; vl += 16) {
           const float x = lr[vl];
-          if (x > best || (x == best && v0 + vl < bi)) { best = x; bi = v0 + vl; }
+          if (x > best) { best = x; bi = v0 + vl; }   // (ascending vl per lane: the first maximum stays)
         }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
+      for (int o = 8; o > 0; o >>= 1) {
         const float ob = __shfl_xor(best, o, 64);
         const int oi = __shfl_xor(bi, o, 64);
         if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
       }
       float se = 0.f;
-      if (a.dump != nullptr && f < W && v1 > v0) {
-        for (int vl = lane; v0 + vl < v1; vl += 64) se += expf(lr[vl] - best);
-        se = gam_wave_sum(se);
+      if (a.dump != nullptr) {
+        if (f < W)
+          for (int vl = li; v0 + vl < v1; vl += 16) se += expf(lr[vl] - best);
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
       }
-      if (lane == 0) {
+      if (li == 0) {
         if (C > 1) {
           unsigned long long* q = xa + (((size_t)par_a * C + cm) * GAM_RC_WIN + f) * 3;
           gam_rc_put(q + 0, best, xc);
           gam_rc_put(q + 1, __int_as_float(bi), xc);
-          gam_rc_put(q + 2, se, xc);
+          if (NG == 3) gam_rc_put(q + 2, se, xc);
         } else {
           apart[f * 3 + 0] = best; apart[f * 3 + 1] = __int_as_float(bi); apart[f * 3 + 2] = se;
         }
       }
     }
     if (C > 1) {
-      for (int i = tid; i < C * GAM_RC_WIN * 3; i += 256) {
-        float v;
-        if (!gam_rc_get(xa + (size_t)par_a * C * GAM_RC_WIN * 3 + i, xc, v, g.status)) { dead_s[0] = 1; v = 0.f; }
-        apart[i] = v;
+      const int n = C * GAM_RC_WIN * NG;
+      for (int i = tid; i < n; i += 512) {
+        float va = 0.f, vb = 0.f;
+        const bool two = i + 256 < n;
+        const int ia = i / NG * 3 + i % NG, ib = (i + 256) / NG * 3 + (i + 256) % NG;
+        const unsigned long long* base = xa + (size_t)par_a * C * GAM_RC_WIN * 3;
+        if (!gam_rc_get2(base + ia, base + ib, two, xc, va, vb, g.status)) { dead_s[0] = 1; va = vb = 0.f; }
+        apart[ia] = va;
+        if (two) apart[ib] = vb;
       }
       par_a ^= 1;
     }
     __syncthreads();
+    GAM_RC_MARK(T_XA);
     if (dead_s[0]) { dead = true; break; }
     if (tid < GAM_RC_WIN) {   // combine the members' slices (ascending class order: the first maximum wins)
       const int f = tid;
@@ -396,6 +485,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       lse_s[f] = M + logf(S);
     }
     __syncthreads();
+    GAM_RC_MARK(T_COMB);
     // first non-blank frame of the window (uniform scan, W <= 16)
     int fstar = W;
     for (int f = 0; f < W; ++f)
@@ -425,14 +515,22 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       ++n_out;
       ++sym;
       label = k;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) tabv[j] = a.gate_tab[(size_t)label * 4 * H + grow[j]];   // lands while the round finishes
       for (int i = tid; i < H; i += 256) h_s[i] = hn_s[i];
       for (int ii = tid; i0 + ii < i1; ii += 256) c_s[ii] = cn_s[ii];
       need_pred = true;
       if (sym >= a.max_symbols) { t = te + 1; sym = 0; }   // frame advances regardless (decoding.py:189-205)
       else t = te;
     }
+    if (t < len) fetch_window(t);
     __syncthreads();
+    GAM_RC_MARK(T_CTRL);
   }
+#if GAM_RC_TIMING
+  if (b == 0 && cm == 0 && tid == 0)
+    for (int i = 1; i <= T_ROUNDS; ++i) g.status[i] = (int)tacc[i];
+#endif
   if (cm == 0 && tid == 0) {
     a.counts[b] = dead ? -1 : (n_out < a.cap ? n_out : a.cap);
     if (a.dump_count != nullptr) a.dump_count[b] = n_dump;
