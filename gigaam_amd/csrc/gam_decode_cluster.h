@@ -466,8 +466,12 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
     __syncthreads();
     GAM_RC_MARK(T_XA);
     if (dead_s[0]) { dead = true; break; }
-    if (tid < GAM_RC_WIN) {   // combine the members' slices (ascending class order: the first maximum wins)
-      const int f = tid;
+    // combine the members' slices (ascending class order: the first maximum wins).  Every wave does it for all 16
+    // frames (lane & 15 = frame), so the window's verdict needs no further barrier: a ballot gives the first
+    // non-blank frame, a lane read its label
+    int fstar, kstar;
+    {
+      const int f = li;
       float M = -INFINITY;
       int bi = 0x7fffffff;
       for (int c = 0; c < C; ++c) {
@@ -475,21 +479,20 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
         const int ix = __float_as_int(apart[(c * GAM_RC_WIN + f) * 3 + 1]);
         if (m > M || (m == M && ix < bi)) { M = m; bi = ix; }
       }
-      float S = 0.f;
-      if (a.dump != nullptr)
+      const unsigned nb = (unsigned)(__ballot(f < W && bi != blank) & 0xffffull);
+      fstar = nb != 0u ? __builtin_ctz(nb) : W;
+      kstar = __shfl(bi, fstar & 15, 64);
+      if (a.dump != nullptr) {
+        float S = 0.f;
         for (int c = 0; c < C; ++c) {
           const float m = apart[(c * GAM_RC_WIN + f) * 3 + 0];
           if (m > -INFINITY) S += apart[(c * GAM_RC_WIN + f) * 3 + 2] * expf(m - M);
         }
-      lab_s[f] = bi;
-      lse_s[f] = M + logf(S);
+        if (tid < GAM_RC_WIN) lse_s[f] = M + logf(S);
+        __syncthreads();
+      }
     }
-    __syncthreads();
     GAM_RC_MARK(T_COMB);
-    // first non-blank frame of the window (uniform scan, W <= 16)
-    int fstar = W;
-    for (int f = 0; f < W; ++f)
-      if (lab_s[f] != blank) { fstar = f; break; }
     const int n_eval = fstar < W ? fstar + 1 : W;   // joint evaluations the sequential loop performs
     if (a.dump != nullptr) {
       for (int f = 0; f < n_eval; ++f) {
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       t += W;
       sym = 0;
     } else {                     // emission at frame t + fstar (decoding.py:175-178)
-      const int k = lab_s[fstar];
+      const int k = kstar;
       const int te = t + fstar;
       if (fstar > 0) sym = 0;
       if (cm == 0 && tid == 0 && n_out < a.cap) {
@@ -517,8 +520,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       label = k;
 #pragma unroll
       for (int j = 0; j < NR; ++j) tabv[j] = a.gate_tab[(size_t)label * 4 * H + grow[j]];   // lands while the round finishes
-      for (int i = tid; i < H; i += 256) h_s[i] = hn_s[i];
-      for (int ii = tid; i0 + ii < i1; ii += 256) c_s[ii] = cn_s[ii];
+      { float* x = h_s; h_s = hn_s; hn_s = x; x = c_s; c_s = cn_s; cn_s = x; }   // commit (h', c'): swap the buffers
       need_pred = true;
       if (sym >= a.max_symbols) { t = te + 1; sym = 0; }   // frame advances regardless (decoding.py:189-205)
       else t = te;
