@@ -88,39 +88,96 @@ __global__ __launch_bounds__(256) void gam_attn_f16x3_kernel(GamAttnArgs a) {
   float mrun[2] = {-INFINITY, -INFINITY};
   float lsum[2] = {0.f, 0.f};
 
-  for (int kt0 = 0; kt0 < klen; kt0 += GAM_ATT_KT) {
-    // ---- stage K [64][48] and V^T [48][64] as fp16 hi/lo planes ----
+  // K / V rows of a key tile: fetched into registers one tile AHEAD (in flight under the previous tile's MFMAs),
+  // split and written to LDS at the top of their own iteration
+  float4 kreg[3], vreg[2][2];
+  auto fetch_tile = [&](int kt0) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int idx = tid + i * 256;       // 0..767
       const int kr = idx / 12, c4 = (idx - kr * 12) * 4;
       int key = kt0 + kr;
       key = key < a.Ta ? key : a.Ta - 1;
-      const float4 kv = *reinterpret_cast<const float4*>(a.k + (rowbase + key) * a.ldq + h * DK + c4);
-      gam_half4 hi, lo;
-      gam_split4((f32x4){kv.x, kv.y, kv.z, kv.w}, hi, lo);
-      *reinterpret_cast<gam_half4*>(&Kh[kr * GAM_A16_KLD + c4]) = hi;
-      *reinterpret_cast<gam_half4*>(&Kl[kr * GAM_A16_KLD + c4]) = lo;
+      kreg[i] = *reinterpret_cast<const float4*>(a.k + (rowbase + key) * a.ldq + h * DK + c4);
     }
-    // V^T: one item = 2 neighbouring keys x 4 channels -> per channel one 4-byte write per plane
-    for (int it = tid; it < 32 * 12; it += 256) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int it = tid + i * 256;
+      it = it < 32 * 12 ? it : 32 * 12 - 1;
       const int kp = it / 12, c4 = (it - kp * 12) * 4;
       int k0 = kt0 + 2 * kp, k1 = k0 + 1;
       k0 = k0 < a.Ta ? k0 : a.Ta - 1;
       k1 = k1 < a.Ta ? k1 : a.Ta - 1;
-      const float4 v0 = *reinterpret_cast<const float4*>(a.v + (rowbase + k0) * a.ldv + h * DK + c4);
-      const float4 v1 = *reinterpret_cast<const float4*>(a.v + (rowbase + k1) * a.ldv + h * DK + c4);
-      gam_half4 h0, l0, h1, l1;
-      gam_split4((f32x4){v0.x, v0.y, v0.z, v0.w}, h0, l0);
-      gam_split4((f32x4){v1.x, v1.y, v1.z, v1.w}, h1, l1);
-      typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        *reinterpret_cast<half2_t*>(&Vh[(c4 + e) * GAM_A16_VLD + 2 * kp]) = (half2_t){h0[e], h1[e]};
-        *reinterpret_cast<half2_t*>(&Vl[(c4 + e) * GAM_A16_VLD + 2 * kp]) = (half2_t){l0[e], l1[e]};
+      vreg[i][0] = *reinterpret_cast<const float4*>(a.v + (rowbase + k0) * a.ldv + h * DK + c4);
+      vreg[i][1] = *reinterpret_cast<const float4*>(a.v + (rowbase + k1) * a.ldv + h * DK + c4);
+    }
+  };
+  if (!REL && klen > 0) fetch_tile(0);
+
+  for (int kt0 = 0; kt0 < klen; kt0 += GAM_ATT_KT) {
+    if constexpr (REL) {   // (no look-ahead: the REL fragments leave no registers for it)
+      // ---- stage K [64][48] and V^T [48][64] as fp16 hi/lo planes ----
+  #pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int idx = tid + i * 256;       // 0..767
+        const int kr = idx / 12, c4 = (idx - kr * 12) * 4;
+        int key = kt0 + kr;
+        key = key < a.Ta ? key : a.Ta - 1;
+        const float4 kv = *reinterpret_cast<const float4*>(a.k + (rowbase + key) * a.ldq + h * DK + c4);
+        gam_half4 hi, lo;
+        gam_split4((f32x4){kv.x, kv.y, kv.z, kv.w}, hi, lo);
+        *reinterpret_cast<gam_half4*>(&Kh[kr * GAM_A16_KLD + c4]) = hi;
+        *reinterpret_cast<gam_half4*>(&Kl[kr * GAM_A16_KLD + c4]) = lo;
+      }
+      // V^T: one item = 2 neighbouring keys x 4 channels -> per channel one 4-byte write per plane
+      for (int it = tid; it < 32 * 12; it += 256) {
+        const int kp = it / 12, c4 = (it - kp * 12) * 4;
+        int k0 = kt0 + 2 * kp, k1 = k0 + 1;
+        k0 = k0 < a.Ta ? k0 : a.Ta - 1;
+        k1 = k1 < a.Ta ? k1 : a.Ta - 1;
+        const float4 v0 = *reinterpret_cast<const float4*>(a.v + (rowbase + k0) * a.ldv + h * DK + c4);
+        const float4 v1 = *reinterpret_cast<const float4*>(a.v + (rowbase + k1) * a.ldv + h * DK + c4);
+        gam_half4 h0, l0, h1, l1;
+        gam_split4((f32x4){v0.x, v0.y, v0.z, v0.w}, h0, l0);
+        gam_split4((f32x4){v1.x, v1.y, v1.z, v1.w}, h1, l1);
+        typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+  #pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          *reinterpret_cast<half2_t*>(&Vh[(c4 + e) * GAM_A16_VLD + 2 * kp]) = (half2_t){h0[e], h1[e]};
+          *reinterpret_cast<half2_t*>(&Vl[(c4 + e) * GAM_A16_VLD + 2 * kp]) = (half2_t){l0[e], l1[e]};
+        }
+      }
+    } else {
+      // ---- stage K [64][48] and V^T [48][64] as fp16 hi/lo planes ----
+  #pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int idx = tid + i * 256;
+        const int kr = idx / 12, c4 = (idx - kr * 12) * 4;
+        gam_half4 hi, lo;
+        gam_split4((f32x4){kreg[i].x, kreg[i].y, kreg[i].z, kreg[i].w}, hi, lo);
+        *reinterpret_cast<gam_half4*>(&Kh[kr * GAM_A16_KLD + c4]) = hi;
+        *reinterpret_cast<gam_half4*>(&Kl[kr * GAM_A16_KLD + c4]) = lo;
+      }
+      // V^T: one item = 2 neighbouring keys x 4 channels -> per channel one 4-byte write per plane
+  #pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int it = tid + i * 256;
+        if (it < 32 * 12) {
+          const int kp = it / 12, c4 = (it - kp * 12) * 4;
+          gam_half4 h0, l0, h1, l1;
+          gam_split4((f32x4){vreg[i][0].x, vreg[i][0].y, vreg[i][0].z, vreg[i][0].w}, h0, l0);
+          gam_split4((f32x4){vreg[i][1].x, vreg[i][1].y, vreg[i][1].z, vreg[i][1].w}, h1, l1);
+          typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            *reinterpret_cast<half2_t*>(&Vh[(c4 + e) * GAM_A16_VLD + 2 * kp]) = (half2_t){h0[e], h1[e]};
+            *reinterpret_cast<half2_t*>(&Vl[(c4 + e) * GAM_A16_VLD + 2 * kp]) = (half2_t){l0[e], l1[e]};
+          }
+        }
       }
     }
     __syncthreads();
+    if (!REL && kt0 + GAM_ATT_KT < klen) fetch_tile(kt0 + GAM_ATT_KT);
 
     // ---- S^T[kb][j] = K_kb . Q_j^T  (6 MFMAs per 16x16 tile) ----
     f32x4 st[4][2];
