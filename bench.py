@@ -448,6 +448,18 @@ def main():
         }
         line["kernel_classes_ms_per_step"] = {k: round(v["ms"], 3) for k, v in prof_all.items() if v["launches"]}
         line["kernel_classes_note"] = "HIP-event time per class from one extra untimed step"
+        if is_rnnt and cfgno == 3 and "decode" in prof_all:
+            # the greedy loop is latency-bound -- report joint evaluations ("steps": one per frame + one per
+            # emitted token, decoding.py:162-205) per second and the time per step on the longest utterance's chain
+            with torch.no_grad():
+                elen = eng.encode(*eng.frontend(wav, wlen))[1].cpu().tolist()
+            steps = [int(e) + len(i) for e, (i, _) in zip(elen, decoded_mine)]
+            dec_ms = prof_all["decode"]["ms"]
+            line["rnnt_decode"] = {"ms_per_batch": round(dec_ms, 3), "joint_steps_per_batch": int(sum(steps)),
+                                   "steps_per_s": round(sum(steps) / (dec_ms * 1e-3)),
+                                   "us_per_step_longest_utterance": round(dec_ms * 1e3 / max(1, max(steps)), 3),
+                                   "note": "768->320 projection GEMM + gam_rnnt_cluster_kernel; the utterances of a batch decode "
+                                           "concurrently (one workgroup cluster each), a 16-frame window per hand-off round"}
         if cfgno in (2, 3):
             whole = FLOP_PER_UTT_20S_V2 * (args.seconds / 20.0) * (g1 - g0) / (ms_step * 1e-3) / 1e12
             line["whole_path_tflops_per_gpu"] = round(whole, 2)

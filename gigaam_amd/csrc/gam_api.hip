@@ -99,6 +99,7 @@ struct gam_handle {
   float *lstm_whh_q = nullptr, *jn_pred_q = nullptr;   // [k/4][row][4] re-layouts for the cluster decode kernel
   int use_rowscale = 1;         // GAM_ROWSCALE=0: no per-row pre-scale of the LayerNorm-produced GEMM operands (A/B switch)
   int use_range = 1;            // GAM_RANGE=0: no range guard on the unscaled operands (A/B switch)
+  int ncu = 256;                // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int rnnt_cluster = -1;        // GAM_RNNT_CLUSTER: 0 = one workgroup per utterance, N = force N per utterance, -1 = auto
   DevBuf rnnt_x;                // hand-off granules + status word of the cluster kernel
 
@@ -377,6 +378,10 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   if (const char* e = getenv("GAM_SPLITK")) h->use_splitk = atoi(e);
   if (const char* e = getenv("GAM_GRAPH")) h->use_graph = atoi(e);
   if (const char* e = getenv("GAM_RNNT_CLUSTER")) h->rnnt_cluster = atoi(e);
+  {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && n > 0) h->ncu = n;
+  }
   if (const char* e = getenv("GAM_ROWSCALE")) h->use_rowscale = atoi(e);
   if (const char* e = getenv("GAM_RANGE")) h->use_range = atoi(e);
   if (const char* e = getenv("GAM_GEMM_MODE")) h->gemm_mode = (strcmp(e, "f32") == 0) ? GAM_GEMM_F32 : GAM_GEMM_F16X3;
@@ -1160,7 +1165,9 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
   // (8 utterance columns, one per XCD; C members of a cluster share an XCD.)
   {
     const int nu8 = gam_cdiv(B, 8);
-    int C = (256 - 16) / (8 * nu8);   // one workgroup per CU with a few CUs to spare (members spin on each other)
+    // every member of every cluster must be resident at once (they spin on each other): at most one workgroup per CU
+    // of THIS device, with a few CUs to spare; a partition with fewer CUs gets smaller clusters or the one-workgroup kernel
+    int C = (h->ncu - 16) / (8 * nu8);
     C = C > 8 ? 8 : C;
     if (h->rnnt_cluster >= 0) C = h->rnnt_cluster < C ? h->rnnt_cluster : C;
     if (C >= 1 && JH % 16 == 0 && a.H % 4 == 0) {   // (JH % 16: MFMA k-steps and the LDS-DMA window)
