@@ -49,6 +49,7 @@ from gigaam_amd.shard import shard_range  # noqa: E402,F401  (re-exported: tests
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 F16_MFMA_PEAK_TFLOPS = 2500.0   # same guide: dense fp16/bf16 MFMA (32x32x16)
+PEAK_SCLK_MHZ = 2400.0          # same guide: the boost clock the peaks are quoted at
 FLOP_PER_UTT_20S_V2 = 325.9e9   # SURVEY.md §8d / BASELINE.md §3
 
 
@@ -108,6 +109,107 @@ def make_gather(kind: str, rank: int, n_ranks: int, dev: torch.device):
         mv = lambda t: None if t is None else t.to(dev)  # noqa: E731
         return shard.torch_gather(mv(index), mv(counts), mv(ids), mv(frames))
     return tg, "torch.distributed all_gather (RCCL)"
+
+
+
+# ----------------------------------------------------------------------------- board power / clock (amdgpu hwmon)
+def _hwmon_dir(dev_index: int):
+    """The amdgpu hwmon directory of torch device ``dev_index`` (matched by PCI address), or None."""
+    import glob
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        want = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+    except Exception:
+        want = None
+    cands = []
+    for d in sorted(glob.glob("/sys/class/drm/card*/device")):
+        hw = sorted(glob.glob(os.path.join(d, "hwmon", "hwmon*")))
+        if not hw:
+            continue
+        real = os.path.basename(os.path.realpath(d))
+        cands.append((real, hw[0]))
+    for real, hw in cands:
+        if want and real.startswith(want):
+            return hw
+    return cands[0][1] if len(cands) == 1 else None
+
+
+class PowerSampler:
+    """Samples board power (power1_average / power1_input, microwatts) and the shader clock (freq1_input, Hz) from the
+    amdgpu hwmon files while a few untimed steps run: the measurement behind DESIGN's "the GEMM loop is power-limited"."""
+
+    def __init__(self, dev_index: int, period_s: float = 0.01):
+        import threading
+        import shutil
+        self.hw = _hwmon_dir(dev_index)
+        self.smi = None if self.hw else (shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None))
+        self.raw = None
+        self.period = period_s
+        self.samples = []
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except Exception:
+            return None
+
+    def _run_smi(self):
+        """Fallback when sysfs is hidden: poll ``rocm-smi -P -c --json`` (a few samples per second)."""
+        import re
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                txt = subprocess.run([self.smi, "-P", "-c", "--json"], capture_output=True, text=True, timeout=5).stdout
+                card = next(iter(json.loads(txt).values()))
+                if self.raw is None:
+                    self.raw = card
+                w = next((float(v) for k, v in card.items() if "ower" in k and "(W)" in k and re.fullmatch(r"[0-9.]+", str(v))), None)
+                f = next((float(re.search(r"([0-9.]+)\s*Mhz", str(v), re.I).group(1)) for k, v in card.items()
+                          if k.lower().startswith("sclk") and re.search(r"[0-9.]+\s*Mhz", str(v), re.I)), None)
+                self.samples.append((w * 1e6 if w else None, f * 1e6 if f else None))
+            except Exception:
+                self.samples.append((None, None))
+
+    def _run(self):
+        if not self.hw:
+            return self._run_smi()
+        pw = next((p for p in ("power1_average", "power1_input") if os.path.exists(os.path.join(self.hw, p))), None)
+        while not self._stop.is_set():
+            w = self._read(os.path.join(self.hw, pw)) if pw else None
+            f = self._read(os.path.join(self.hw, "freq1_input"))
+            self.samples.append((w, f))
+            time.sleep(self.period)
+
+    def __enter__(self):
+        if self.hw or self.smi:
+            self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        if self.hw or self.smi:
+            self._th.join(timeout=6.0)
+
+    def summary(self):
+        if not self.hw and not self.smi:
+            return {"available": False, "note": "neither an amdgpu hwmon directory nor rocm-smi is visible here"}
+        ws = [w * 1e-6 for w, _ in self.samples if w]
+        fs = [f * 1e-6 for _, f in self.samples if f]
+        cap = self._read(os.path.join(self.hw, "power1_cap")) if self.hw else None
+        out = {"available": bool(ws or fs), "samples": len(self.samples), "source": self.hw or (self.smi + " -P -c --json")}
+        if not ws and not fs and self.raw is not None:
+            out["unparsed_sample"] = {k: str(v)[:40] for k, v in list(self.raw.items())[:12]}
+        if ws:
+            out.update(avg_w=round(sum(ws) / len(ws), 1), max_w=round(max(ws), 1))
+        if cap:
+            out["cap_w"] = round(cap * 1e-6, 1)
+        if fs:
+            out.update(avg_sclk_mhz=round(sum(fs) / len(fs)), min_sclk_mhz=round(min(fs)), max_sclk_mhz=round(max(fs)))
+        return out
 
 
 # ----------------------------------------------------------------------------- cpu baseline
@@ -199,6 +301,7 @@ def main():
     ap.add_argument("--rnnt-blank-bias", type=float, default=None,
                     help="RNN-T models: blank bias of the synthetic joint (default: the blank-dominant value of tests/golden/fullsize_meta.json)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
+    ap.add_argument("--no-power", action="store_true", help="skip the board power / shader clock sampling leg")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the exact-fp32 re-timing (roofline_f32_exact)")
     ap.add_argument("--gemm", default="f16x3", choices=["f16x3", "f32"],
                     help="dense-contraction arithmetic: split-fp16 MFMA (fp32-equivalent, default) or exact fp32 MFMA")
@@ -368,6 +471,17 @@ def main():
         prof_all = eng.profile_read()
         eng.profile_enable(0)
 
+    # board power and shader clock over ~2 s of untimed steps (one rank: the hwmon files are per board)
+    power = None
+    if n_ranks == 1 and not args.no_power and cfgno in (2, 3):
+        n_pw = max(5, int(2.0 / max(1e-3, dt / args.steps)))
+        with PowerSampler(dev.index or 0) as ps:
+            for _ in range(n_pw):
+                step()
+            torch.cuda.synchronize()
+        power = ps.summary()
+        power["steps_sampled"] = n_pw
+
     # exact-fp32 leg: the same steps with the dense contractions on v_mfma_f32_32x32x2_f32 (the reference's arithmetic)
     f32_leg = None
     if args.gemm == "f16x3" and not args.no_f32_leg and cfgno in (2, 3):
@@ -463,6 +577,15 @@ def main():
         if cfgno in (2, 3):
             whole = FLOP_PER_UTT_20S_V2 * (args.seconds / 20.0) * (g1 - g0) / (ms_step * 1e-3) / 1e12
             line["whole_path_tflops_per_gpu"] = round(whole, 2)
+    if power is not None:
+        line["board_power"] = power
+        if power.get("avg_sclk_mhz") and "roofline" in line and line["roofline"]["bound"] == "mfma":
+            # the peak is quoted at the 2400 MHz boost clock; under this load the board sits at its power cap and the
+            # shader clock is held lower -- the fraction of what the matrix cores can issue AT THAT CLOCK is reported next
+            # to `frac` (never instead of it)
+            r = line["roofline"]
+            r["avg_sclk_mhz_under_load"] = power["avg_sclk_mhz"]
+            r["frac_at_measured_clock"] = round(r["frac"] * PEAK_SCLK_MHZ / power["avg_sclk_mhz"], 4)
     if f32_leg is not None:
         dt32, out32, p32 = f32_leg
         leg = {"ms_per_step": round(dt32 / args.steps * 1e3, 3), "value": round(audio_s * args.steps / dt32, 1),
