@@ -550,3 +550,40 @@ def test_batch_feeder_matches_reference_collate():
         torch.cuda.synchronize()
         out += [wav[j, : int(n)].cpu() for j, n in enumerate(lens.cpu().tolist())]
     assert len(out) == 11 and all(torch.equal(a, b) for a, b in zip(out, segs))
+
+
+@pytest.mark.parametrize("case", ["v2_ctc_l2", "v3_ctc_l2", "v1_ctc_l2"])
+def test_long_utterance_and_length_limit(case):
+    """A 100 s utterance (T' = 2500: 40 key tiles per query block, 2T'-1 = 4999 relative positions for v1) batched with
+    a 7 s one: lengths, encoder output and CTC log-probs against the CPU oracle at the usual bars.  (ids are not
+    compared here: over 2500 frames of a random-init head the oracle's own top-2 margin falls to 1e-6..1e-4, below any
+    fp32 implementation's reproducibility; the bit-exact ids checks run on the margin-selected goldens.)  Past
+    pos_emb_max_len encoder frames the reference's PE slice comes up short (encoder.py:357-361, 606-607): here a clean
+    error."""
+    from gigaam_amd import synth
+    from gigaam_amd._lib import GigaAMHipError
+    ck, _, _, _ = load_case(case)
+    wav, _ = synth.synth_audio(2, 100.0, seed=31)
+    wlen = torch.tensor([wav.shape[1], 7 * 16000 + 123])
+    eng = _engine(ck)
+    feat_o, flen_o = oracle_features(ck, wav, wlen)
+    feat, flen = eng.frontend(wav, wlen)
+    assert flen.cpu().tolist() == flen_o.tolist()
+    assert logmel_err(feat.cpu(), feat_o, valid_mask(feat_o.shape[2], flen_o))[0] < TOL_FEAT
+    enc, elen = eng.encode(feat_o, flen_o)          # (the oracle's features in, as in test_encoder_matches_reference_golden)
+    logp = eng.ctc_head(enc)
+    with torch.no_grad():
+        enc_ref, elen_ref = O.encoder_forward(ck["state_dict"], ck["cfg"]["encoder"], feat_o, flen_o)
+        logp_ref = O.ctc_log_probs(ck["state_dict"], enc_ref)
+    assert elen.cpu().tolist() == elen_ref.tolist()
+    m = valid_mask(enc_ref.shape[2], elen_ref)
+    err = float(((enc.cpu() - enc_ref).abs() * m[:, None, :]).max())
+    err_lp = float(((logp.cpu() - logp_ref).abs() * m[:, :, None]).max())
+    report("long_utterance", case=case, frames=int(elen_ref.max()), enc_err=err, logp_err=err_lp)
+    assert err < TOL_ENC, (case, err)
+    assert err_lp < TOL_LOGP, (case, err_lp)
+    # 201 s -> 5026 encoder frames > pos_emb_max_len = 5000
+    too_long = torch.zeros(1, 201 * 16000)
+    f2, l2 = eng.frontend(too_long, torch.tensor([too_long.shape[1]]))
+    with pytest.raises(GigaAMHipError, match="pos_emb_max_len"):
+        eng.encode(f2, l2)
