@@ -587,3 +587,42 @@ def test_long_utterance_and_length_limit(case):
     f2, l2 = eng.frontend(too_long, torch.tensor([too_long.shape[1]]))
     with pytest.raises(GigaAMHipError, match="pos_emb_max_len"):
         eng.encode(f2, l2)
+
+
+@pytest.mark.parametrize("case,seed", [("v2_rnnt_l2", 56), ("v3_e2e_rnnt_l2", 54)])
+def test_rnnt_long_utterance(case, seed):
+    """RNN-T greedy over a 60 s utterance (1500 frames, 300-800 tokens, ~2100-2650 joint evaluations -- 20x the
+    goldens' length, so tags, parities and the 16-frame windows of the cluster decode turn over hundreds of times)
+    batched with a 9 s one, against the oracle's decode: ids, frames, step counts and every joint log-prob.  The seeds
+    were chosen so that the oracle's own top-1/top-2 margin stays above RNNT_MIN_MARGIN on every step (asserted)."""
+    from common import RNNT_MIN_MARGIN
+    from gigaam_amd import synth
+    ck, _, _, _ = load_case(case)
+    cfg, sd = ck["cfg"], ck["state_dict"]
+    ms = cfg["decoding"]["max_symbols_per_step"]
+    wav, _ = synth.synth_audio(2, 60.0, seed=seed)
+    wlen = torch.tensor([wav.shape[1], 9 * 16000 + 77])
+    feat_o, flen_o = oracle_features(ck, wav, wlen)
+    with torch.no_grad():
+        enc_o, elen_o = O.encoder_forward(sd, cfg["encoder"], feat_o, flen_o)
+        trace = []
+        ref = O.rnnt_greedy(sd, enc_o, elen_o, ms, cfg["head"]["decoder"]["pred_rnn_layers"], trace=trace)
+    want = [torch.stack([lp for (i, _, lp) in trace if i == b]) for b in range(2)]
+    margin = min(float((w.topk(2, dim=-1).values[:, 0] - w.topk(2, dim=-1).values[:, 1]).min()) for w in want)
+    assert margin > RNNT_MIN_MARGIN, margin
+    eng = _engine(ck)
+    cap = max(w.shape[0] for w in want)
+
+    def check(enc, elen, what):
+        ids, frames, counts, dump, dcount = eng.rnnt_greedy(enc, elen, ms, dump_cap=cap)
+        assert ragged_from_device(ids, frames, counts) == ref, what
+        assert dcount.cpu().tolist() == [w.shape[0] for w in want], what
+        for i, w in enumerate(want):
+            err = float((dump[i, : w.shape[0]].cpu() - w).abs().max())
+            report("rnnt_long_utterance", case=case, what=what, utt=i, steps=int(w.shape[0]), tokens=len(ref[i][0]), err=err, margin=margin)
+            assert err < TOL_LOGP, (what, i, err)
+
+    check(enc_o, elen_o, "decoder alone")
+    feat, flen = eng.frontend(wav, wlen)
+    check(*eng.encode(feat, flen), "whole path")
+    assert ragged_from_device(*eng.rnnt_greedy(enc_o, elen_o, ms)) == ref
