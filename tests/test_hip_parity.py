@@ -626,3 +626,21 @@ def test_rnnt_long_utterance(case, seed):
     feat, flen = eng.frontend(wav, wlen)
     check(*eng.encode(feat, flen), "whole path")
     assert ragged_from_device(*eng.rnnt_greedy(enc_o, elen_o, ms)) == ref
+
+
+@pytest.mark.parametrize("copies", [14, 33, 90])
+def test_rnnt_batch_sizes_and_cluster_mapping(copies):
+    """The cluster decode picks its size from the batch (gam_api.hip: C = min(8, (CUs - 16) / (8 ceil(B / 8)))) and maps
+    workgroup -> (utterance, member) through the XCD-aware rule of gam_decode_cluster.h.  The golden's 3 utterances
+    tiled to B = 42 (C = 5), 99 (C = 2) and 270 (C = 0: the one-workgroup kernel): every copy must decode to the
+    reference's ids and frames."""
+    ck, _, _, gold = load_case("v2_rnnt_l2")
+    eng = _engine(ck)
+    ms = ck["cfg"]["decoding"]["max_symbols_per_step"]
+    ref = split_ragged(gold["ids"], gold["frames"], gold["counts"].tolist())
+    enc = torch.from_numpy(gold["encoded"]).repeat(copies, 1, 1)
+    elen = torch.from_numpy(gold["enc_len"]).repeat(copies)
+    got = ragged_from_device(*eng.rnnt_greedy(enc, elen, ms))
+    assert len(got) == 3 * copies
+    bad = [i for i, g in enumerate(got) if g != ref[i % 3]]
+    assert not bad, bad[:10]
