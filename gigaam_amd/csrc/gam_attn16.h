@@ -30,7 +30,7 @@ __device__ __forceinline__ void gam_split8(const float (&v)[8], gam_half8& hi, g
 // tile as G[m][query] = P(rlo + m).(q + v) for the 80 relative positions the (16 queries x 64 keys)
 // block touches -- same three-term split, P rows split on the fly -- and skewed into S^T through LDS.
 template <bool REL>
-__global__ __launch_bounds__(256) void gam_attn_f16x3_kernel(GamAttnArgs a) {
+__global__ __launch_bounds__(256, 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
   a.scale *= 1.44269504088896341f;   // softmax via 2^x: p = 2^(s*log2e - m)
   __shared__ float Gs[REL ? 4 * 80 * 17 : 1];   // per wave: (q+v).P for 80 relative positions x 16 queries
   __shared__ __attribute__((aligned(16))) _Float16 Kh[GAM_ATT_KT * GAM_A16_KLD];
