@@ -29,8 +29,12 @@ __device__ __forceinline__ void gam_split8(const float (&v)[8], gam_half8& hi, g
 //   S[i,j] = ((q_i + u).k_j + (q_i + v).P(i - j)) / sqrt(d_k); the second term is evaluated per key
 // tile as G[m][query] = P(rlo + m).(q + v) for the 80 relative positions the (16 queries x 64 keys)
 // block touches -- same three-term split, P rows split on the fly -- and skewed into S^T through LDS.
+#ifndef GAM_ATT_NJ
+#define GAM_ATT_NJ 2   // 16-query sub-blocks per wave (A/B switch: 1 = 64 queries per workgroup, twice the waves per SIMD)
+#endif
 template <bool REL>
-__global__ __launch_bounds__(256, 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
+__global__ __launch_bounds__(256, GAM_ATT_NJ == 1 ? 4 : 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
+  constexpr int NJ = GAM_ATT_NJ;
   a.scale *= 1.44269504088896341f;   // softmax via 2^x: p = 2^(s*log2e - m)
   __shared__ float Gs[REL ? 4 * 80 * 17 : 1];   // per wave: (q+v).P for 80 relative positions x 16 queries
   __shared__ __attribute__((aligned(16))) _Float16 Kh[GAM_ATT_KT * GAM_A16_KLD];
@@ -44,16 +48,16 @@ __global__ __launch_bounds__(256, 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
   int klen = a.Tv;
   if (a.lens != nullptr) { const int l = a.lens[b]; klen = l < a.Tv ? l : a.Tv; }
   const size_t rowbase = (size_t)b * a.Ta;
-  const int qw0 = blockIdx.x * 128 + wave * 32;
+  const int qw0 = blockIdx.x * (64 * NJ) + wave * (16 * NJ);
 
   // Q fragments (B operand of S^T), pre-scaled: x32 part d = 8*lg .. +7, x16 part d = 32 + 4*lg .. +3
-  gam_half8 qh32[2], ql32[2];
-  gam_half4 qh16[2], ql16[2];
-  gam_half8 gh32[2], gl32[2];   // REL: (q + pos_bias_v) * scale
-  gam_half4 gh16[2], gl16[2];
-  int qrow[2];
+  gam_half8 qh32[NJ], ql32[NJ];
+  gam_half4 qh16[NJ], ql16[NJ];
+  gam_half8 gh32[NJ], gl32[NJ];   // REL: (q + pos_bias_v) * scale
+  gam_half4 gh16[NJ], gl16[NJ];
+  int qrow[NJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int qi = qw0 + j * 16 + li;
     qrow[j] = qi;
     const int qc = qi < a.Ta ? qi : a.Ta - 1;
@@ -80,13 +84,14 @@ __global__ __launch_bounds__(256, 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
     gam_split4((f32x4){v4[0] * a.scale, v4[1] * a.scale, v4[2] * a.scale, v4[3] * a.scale}, qh16[j], ql16[j]);
   }
 
-  f32x4 o[3][2];
+  f32x4 o[3][NJ];
 #pragma unroll
   for (int d = 0; d < 3; ++d)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) o[d][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float mrun[2] = {-INFINITY, -INFINITY};
-  float lsum[2] = {0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) o[d][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float mrun[NJ], lsum[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) { mrun[j] = -INFINITY; lsum[j] = 0.f; }
 
   // K / V rows of a key tile: fetched into registers one tile AHEAD (in flight under the previous tile's MFMAs),
   // split and written to LDS at the top of their own iteration
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
     if (!REL && kt0 + GAM_ATT_KT < klen) fetch_tile(kt0 + GAM_ATT_KT);
 
     // ---- S^T[kb][j] = K_kb . Q_j^T  (6 MFMAs per 16x16 tile) ----
-    f32x4 st[4][2];
+    f32x4 st[4][NJ];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const int ko = (kb * 16 + li) * GAM_A16_KLD;
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
       const gam_half4 kh16 = *reinterpret_cast<const gam_half4*>(&Kh[ko + 32 + 4 * lg]);
       const gam_half4 kl16 = *reinterpret_cast<const gam_half4*>(&Kl[ko + 32 + 4 * lg]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         // Two accumulator chains, one per instruction shape: a 4-pass 16x16x16 MFMA issued
         // right behind an 8-pass 16x16x32 one ON THE SAME accumulator lost the 8-pass result
         // (hipcc 7.2 / gfx950, observed: S came out without its K_hi.Q_hi term).  Same-shape
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
       // ---- S^T[key a][query b] += G[b - a + 63][b],  G[m][b] = P(rlo + m) . (q_b + v) ----
       float* gw = Gs + wave * (80 * 17);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int rlo = (qw0 + j * 16) - kt0 - 63 + (a.Tv - 1);   // pbuf row of m = 0
 #pragma unroll
         for (int mt = 0; mt < 5; ++mt) {
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
 
     // ---- key mask + online softmax (fp32, per query = per lane column) ----
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       float mx = -INFINITY;
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb)
@@ -286,9 +291,9 @@ __global__ __launch_bounds__(256, 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
     // ---- O^T[d][j] += V^T_d . P_j^T over 32-key chunks: slot (lg, e) = key (2c + (e>>2))*16 + 4*lg + (e&3) ----
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      gam_half8 ph[2], pl[2];
+      gam_half8 ph[NJ], pl[NJ];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const float p8[8] = {st[2 * c][j][0], st[2 * c][j][1], st[2 * c][j][2], st[2 * c][j][3],
                              st[2 * c + 1][j][0], st[2 * c + 1][j][1], st[2 * c + 1][j][2], st[2 * c + 1][j][3]};
         gam_split8(p8, ph[j], pl[j]);
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(256, 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
         const gam_half8 vh = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
         const gam_half8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
           o[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[j], o[d][j], 0, 0, 0);
           o[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[j], o[d][j], 0, 0, 0);
           o[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[j], o[d][j], 0, 0, 0);
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
 
   // ---- epilogue: lane (query li, group lg) holds O^T rows d = dt*16 + 4*lg + r ----
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     float l = lsum[j];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
@@ -333,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
 static inline hipError_t gam_launch_attn_mode(const GamAttnArgs& a, int dk, bool split, hipStream_t s) {
   if (!split) return gam_launch_attn(a, dk, s);
   if (dk != GAM_ATT_DK) return hipErrorInvalidValue;
-  dim3 grid(gam_cdiv(a.Ta, 128), a.H, a.B);
+  dim3 grid(gam_cdiv(a.Ta, 64 * GAM_ATT_NJ), a.H, a.B);
   if (a.pbuf != nullptr) hipLaunchKernelGGL(gam_attn_f16x3_kernel<true>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(gam_attn_f16x3_kernel<false>, grid, dim3(256), 0, s, a);
   return hipGetLastError();
