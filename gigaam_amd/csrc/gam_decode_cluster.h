@@ -4,7 +4,7 @@
 // The one-workgroup-per-utterance kernel (gam_decode.h) is bound by what ONE CU can pull out of L2 per
 // step: W_hh (4H x H fp32 = 1.6 MB), W_pred (0.4 MB) and, for SentencePiece vocabularies, W_out
 // (V x JH = 1.3 MB) -- 65 us (V = 34) to 150 us (V = 1025) per emitted symbol, on 32 of 256 CUs.
-// Here C workgroups (C = 8 at 32 utterances: the whole chip) share one utterance:
+// Here C workgroups (C = 7 at 32 utterances: 224 of 256 CUs) share one utterance:
 //   * member c owns H/C hidden units (all four gate rows of each, so the cell update is local), JH/C rows of
 //     W_pred and V/C classes of W_out: every weight byte is read by exactly one CU per step, 16 bytes per lane
 //     ([k/4][row][4] re-layout built at gam_finalize);
@@ -22,8 +22,11 @@
 // Tried and dropped (r02_s6): W_pred by COLUMN slices, each member publishing the partial product of its own h' slice so
 // that the h' gather and the pp reduction share one hand-off -- C x JH granules per step instead of JH made it slower
 // (config 3 decode 4.57 vs 4.13 ms).
-// Same arithmetic per (frame, state) as the single-workgroup kernel: gate sums run k = 0..H-1 in order, the
-// 16-frame joint window is the same v_mfma_f32_16x16x4_f32 product.
+// fp32 throughout; the 16-frame joint window is the same v_mfma_f32_16x16x4_f32 product as in the single-workgroup
+// kernel, with reassociated sums (resident kernel: four k mod 4 partials per gate row as two v_pk_fma_f32 chains; joint
+// tile: four MFMA chains), i.e. logits differ from that kernel at the 1e-6 level -- both are tested against the
+// reference's log-probs (1e-3).  Inside a round only the hand-offs leave the CU: W_hh rows in registers, W_pred rows,
+// the W_out slice (char vocabularies) and the next window's encoder-projection rows (global_load_lds) in LDS.
 #pragma once
 #include "gam_decode.h"
 
@@ -56,26 +59,8 @@ __device__ __forceinline__ void gam_rc_put(unsigned long long* p, float v, unsig
   __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
                      __HIP_MEMORY_SCOPE_AGENT);
 }
-// poll one granule until its tag matches; false on timeout / launch-wide abort
-__device__ __forceinline__ bool gam_rc_get(const unsigned long long* p, unsigned tag, float& v, int* status) {
-  long long t_end = 0;
-  for (unsigned spin = 0;; ++spin) {
-    const unsigned long long g = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((unsigned)(g >> 32) == tag) { v = __uint_as_float((unsigned)g); return true; }
-    if ((spin & 255u) == 255u) {
-      const long long now = wall_clock64();
-      if (t_end == 0) t_end = now + GAM_RC_TIMEOUT_TICKS;
-      if (now > t_end || __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-        atomicOr(status, 1);
-        return false;
-      }
-    }
-    __builtin_amdgcn_s_sleep(1);
-  }
-}
-
-// poll granule p0 and (when ``two``) p1 with both loads in flight: one L2 round trip instead of two for the threads
-// that own two granules of a 320-wide exchange
+// poll granule p0 and (when ``two``) p1 until their tags match, both loads in flight: one L2 round trip instead of two
+// for the threads that own two granules of a 320-wide exchange; false on timeout / launch-wide abort
 __device__ __forceinline__ bool gam_rc_get2(const unsigned long long* p0, const unsigned long long* p1, bool two, unsigned tag,
                                             float& v0, float& v1, int* status) {
   long long t_end = 0;
