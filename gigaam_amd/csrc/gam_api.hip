@@ -216,7 +216,9 @@ float half_bits_to_float(uint16_t x) { return half_to_float(x); }
 
 // W * 2^shift = hi + lo with hi, lo in fp16; the power-of-two scale puts max|W| near 2^8 so
 // that lo (~2^-11 |W|) stays in the normal fp16 range for all but negligible entries.
-int make_split(gam_handle* h, const std::vector<float>& w, W16& out, int K = 0) {
+// conv_taps > 0 (K = conv_taps * C, k = tap * C + c): the sp32 copy orders its k-tiles (32-channel block, tap) -- taps
+// innermost, the order gam_gemm_sp_kernel walks an implicit-GEMM A operand in; the fp16 planes keep k as given.
+int make_split(gam_handle* h, const std::vector<float>& w, W16& out, int K = 0, int conv_taps = 0) {
   float mx = 0.f;
   for (float v : w) mx = std::max(mx, fabsf(v));
   int shift = 0;
@@ -245,7 +247,12 @@ int make_split(gam_handle* h, const std::vector<float>& w, W16& out, int K = 0) 
     std::vector<uint16_t> sp(w.size() * 2);
     for (size_t i = 0; i < w.size(); ++i) {
       const size_t n = i / K, k = i % K;
-      const size_t o = n * 2 * (size_t)K + (k / 32) * 64 + (k % 32);
+      size_t kb = k / 32;
+      if (conv_taps > 0) {
+        const size_t cblocks = (size_t)K / conv_taps / 32, t = kb / cblocks, cb = kb % cblocks;
+        kb = cb * conv_taps + t;
+      }
+      const size_t o = n * 2 * (size_t)K + kb * 64 + (k % 32);
       sp[o] = hi[i];
       sp[o + 32] = lo[i];
     }
@@ -533,7 +540,7 @@ int gam_finalize(gam_handle* h) {
       for (int ci = 0; ci < C; ++ci)
         for (int t = 0; t < 9; ++t) r[((size_t)n * 9 + t) * C + ci] = w2->data[((size_t)n * C + ci) * 9 + t];
     UP(h->c2_w, r);
-    if (make_split(h, r, h->s_c2, 9 * C)) return fail(h, -2, "split upload failed");
+    if (make_split(h, r, h->s_c2, 9 * C, C % 32 == 0 ? 9 : 0)) return fail(h, -2, "split upload failed");
     UP(h->c2_b, b2->data);
     // columns c*f2+f -> f*C+c (encoder.py:126-127 flattens channel-major)
     std::vector<float> l((size_t)D * C * h->f2);
