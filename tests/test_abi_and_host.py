@@ -113,3 +113,18 @@ def test_frames_to_words_and_vad_packing():
     assert out[1] == (18.4, 21.0)
     assert len(out) == 5 and out[2][0] == 30.0 and abs(out[4][1] - 100.0) < 1e-9
     assert all(e - s <= 30.0 + 1e-9 for s, e in out)
+
+
+def test_bench_power_sampler_without_telemetry(monkeypatch):
+    """bench.py's board-power leg must degrade to a labelled "unavailable" record (never an exception) where neither
+    the amdgpu hwmon files nor rocm-smi exist -- e.g. this CPU container."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "_hwmon_dir", lambda i: None)
+    monkeypatch.setattr("shutil.which", lambda name: None)
+    monkeypatch.setattr("os.path.exists", lambda p: False)
+    with bench.PowerSampler(0) as ps:
+        pass
+    out = ps.summary()
+    assert out["available"] is False and "note" in out
