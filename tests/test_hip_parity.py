@@ -644,3 +644,44 @@ def test_rnnt_batch_sizes_and_cluster_mapping(copies):
     assert len(got) == 3 * copies
     bad = [i for i, g in enumerate(got) if g != ref[i % 3]]
     assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("max_duration", [0.5, 1.0])
+def test_different_audio_lengths_v3_e2e_ctc(max_duration):
+    """reference tests/test_batching.py:143-159: v3_e2e_ctc on a batch of two clips of 0.5 x and 1 x max_duration
+    (0.25 s .. 1 s: a handful of encoder frames) must run and return two rows -- here also checked against the oracle."""
+    from gigaam_amd import synth
+    from gigaam_amd.feeder import collate
+    ck = synth.make_checkpoint("v3_e2e_ctc", seed=1, n_layers=2)
+    eng = _engine(ck)
+    wav, wlen = collate([_reference_test_audio(d, seed=i) for i, d in enumerate(np.linspace(max_duration * 0.5, max_duration, 2))])
+    feat_o, flen_o = oracle_features(ck, wav, wlen)
+    enc, elen = eng.encode(*eng.frontend(wav, wlen))
+    assert enc.shape[0] == 2 and bool(torch.isfinite(enc).all())
+    enc2, elen2 = eng.encode(feat_o, flen_o)
+    with torch.no_grad():
+        enc_ref, elen_ref = O.encoder_forward(ck["state_dict"], ck["cfg"]["encoder"], feat_o, flen_o)
+    assert elen.cpu().tolist() == elen_ref.tolist() == elen2.cpu().tolist()
+    m = valid_mask(enc_ref.shape[2], elen_ref)
+    assert float(((enc2.cpu() - enc_ref).abs() * m[:, None, :]).max()) < TOL_ENC
+
+
+def test_longform_consistency(tmp_path):
+    """reference tests/test_longform.py:183-205: two transcribe_longform runs over the same 30 s file give the same
+    segments and boundaries (here: and the same text -- the kernels are deterministic)."""
+    import wave
+    import gigaam_amd
+    from gigaam_amd import synth
+    ck = synth.make_checkpoint("v2_ctc", seed=1, n_layers=2)
+    model = gigaam_amd.model_from_checkpoint(ck, "cuda:0")
+    wav, _ = synth.synth_audio(1, 30.0, seed=12)
+    pcm = (wav[0].numpy() * 32768.0).round().clip(-32768, 32767).astype(np.int16)
+    wpath = str(tmp_path / "long.wav")
+    with wave.open(wpath, "wb") as wf:
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000); wf.writeframes(pcm.tobytes())
+    kw = dict(speech_regions=[(0.3, 7.9), (8.4, 13.0), (13.1, 21.7), (22.5, 29.6)], min_duration=3.0, max_duration=9.0)
+    r1 = model.transcribe_longform(wpath, **kw)
+    r2 = model.transcribe_longform(wpath, **kw)
+    assert len(r1.segments) == len(r2.segments) >= 2
+    for a, b in zip(r1.segments, r2.segments):
+        assert (a.start, a.end) == (b.start, b.end) and a.text == b.text
