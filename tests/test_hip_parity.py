@@ -685,3 +685,49 @@ def test_longform_consistency(tmp_path):
     assert len(r1.segments) == len(r2.segments) >= 2
     for a, b in zip(r1.segments, r2.segments):
         assert (a.start, a.end) == (b.start, b.end) and a.text == b.text
+
+
+@pytest.mark.parametrize("revision", ["v3_ctc", "v3_e2e_ctc"])
+def test_transcribe_result_structure_v3(revision, tmp_path):
+    """reference tests/test_timestamps.py:112-215 on synthetic checkpoints: the structure and ordering invariants of
+    transcribe / transcribe_longform results with and without word timestamps.  v3_e2e_ctc runs with a REAL
+    SentencePiece model (tests/golden/spm256.model: 256 pieces + blank = the head's 257 classes), so the e2e
+    tokenizer path (decoding.py:30-44, timestamps_utils.py:29-53) is exercised end to end on the GPU."""
+    import os
+    import wave
+    import gigaam_amd
+    from common import ROOT
+    from gigaam_amd import synth
+    from gigaam_amd.types import LongformTranscriptionResult, Segment, TranscriptionResult, Word
+    ck = synth.make_checkpoint(revision, seed=1, n_layers=2)
+    if "e2e" in revision:
+        ck["cfg"]["decoding"]["model_path"] = os.path.join(ROOT, "tests", "golden", "spm256.model")
+    model = gigaam_amd.model_from_checkpoint(ck, "cuda:0")
+    wav, _ = synth.synth_audio(1, 12.0, seed=17)
+    pcm = (wav[0].numpy() * 32768.0).round().clip(-32768, 32767).astype(np.int16)
+    wpath = str(tmp_path / "clip.wav")
+    with wave.open(wpath, "wb") as wf:
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000); wf.writeframes(pcm.tobytes())
+
+    plain = model.transcribe(wpath)
+    assert isinstance(plain, TranscriptionResult) and isinstance(str(plain), str) and len(str(plain)) > 0 and plain.words is None
+    res = model.transcribe(wpath, word_timestamps=True)
+    assert isinstance(res, TranscriptionResult) and res.text == plain.text and isinstance(res.words, list) and len(res.words) > 0
+    prev_end = 0.0
+    for w in res.words:
+        assert isinstance(w, Word) and isinstance(w.text, str) and w.start < w.end and w.start >= prev_end - 0.01
+        assert w.end <= 12.0 + 0.04
+        prev_end = w.end
+    assert " ".join(w.text for w in res.words) == " ".join(res.text.split())   # (runs of spaces make no empty words)
+
+    regs = [(0.2, 5.6), (6.1, 11.8)]
+    lf = model.transcribe_longform(wpath, speech_regions=regs, min_duration=2.0, max_duration=7.0)
+    assert isinstance(lf, LongformTranscriptionResult) and len(lf.segments) == 2
+    for seg in lf.segments:
+        assert isinstance(seg, Segment) and isinstance(seg.text, str) and seg.start < seg.end and seg.words is None
+    lfw = model.transcribe_longform(wpath, word_timestamps=True, speech_regions=regs, min_duration=2.0, max_duration=7.0)
+    assert [s.text for s in lfw.segments] == [s.text for s in lf.segments]
+    for seg in lfw.segments:
+        assert seg.words is not None and all(isinstance(w, Word) for w in seg.words)
+        assert all(seg.start - 1e-6 <= w.start < w.end <= seg.end + 0.05 for w in seg.words)
+    assert len(lfw.words) > 0 and all(w.start < w.end for w in lfw.words)
