@@ -105,10 +105,12 @@ def make_gather(kind: str, rank: int, n_ranks: int, dev: torch.device):
         if int(flag.item()) == 1:
             return comm.gather, "gam_gather_ids (RCCL ncclAllGather behind the C ABI)"
 
+    on = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+
     def tg(index, counts, ids, frames):
-        mv = lambda t: None if t is None else t.to(dev)  # noqa: E731
+        mv = lambda t: None if t is None else t.to(on)  # noqa: E731
         return shard.torch_gather(mv(index), mv(counts), mv(ids), mv(frames))
-    return tg, "torch.distributed all_gather (RCCL)"
+    return tg, f"torch.distributed all_gather ({'RCCL' if on.type == 'cuda' else 'gloo: shared-device rehearsal'})"
 
 
 
@@ -215,7 +217,7 @@ class PowerSampler:
 # ----------------------------------------------------------------------------- cpu baseline
 def cpu_baseline(ckpt, wav, wlen, n_utts: int, gpu_decoded, sweep: bool):
     """The CPU oracle (fp32 port of the reference's CPU path) on this box's host cores.  With ``sweep`` the thread
-    count is chosen by timing a small sample at 8 / 32 / 64 / all cores (many small fp32 ops: beyond a few dozen
+    count is chosen by timing a small sample at 8 / 16 / 32 / 64 threads (many small fp32 ops: beyond a few dozen
     threads the oracle gets slower on a many-core host), then all ``n_utts`` utterances run at the best setting.
     Also reports how many of those utterances decode to exactly the GPU's ids/frames."""
     from oracle import gigaam_oracle as O
@@ -227,12 +229,9 @@ def cpu_baseline(ckpt, wav, wlen, n_utts: int, gpu_decoded, sweep: bool):
         torch.set_num_threads(best)
         O.transcribe_ids(ckpt, w[:1, :16000].contiguous(), torch.tensor([16000]))  # warm-up
         if sweep:
-            for th in sorted({min(8, ncpu), min(32, ncpu), min(64, ncpu), ncpu}):
+            for th in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu)}):
                 torch.set_num_threads(th)
-                if th > 64:     # all cores of a many-core host run the oracle far below real time (256 threads: 0.17x
-                    ws, ls = w[:1, :32000].contiguous(), torch.tensor([32000])   # measured on 20 s): a 2 s clip bounds the point
-                else:
-                    ws, ls = w[:min(2, n_utts)], l[:min(2, n_utts)]
+                ws, ls = w[:min(2, n_utts)], l[:min(2, n_utts)]
                 t0 = time.perf_counter()
                 O.transcribe_ids(ckpt, ws, ls)
                 sweep_out[th] = round(float(ls.sum()) / 16000.0 / (time.perf_counter() - t0), 2)
@@ -252,6 +251,12 @@ def cpu_baseline(ckpt, wav, wlen, n_utts: int, gpu_decoded, sweep: bool):
         "reference_cpu": "unavailable on the GPU box (/root/reference is not shipped); the oracle is pinned to the reference's "
                          "own modules by tests/golden/*.npz",
     }
+    rp = os.path.join(ROOT, "profiles", "r03_cpu_ref_vs_port.json")
+    if os.path.exists(rp):   # the reference's own modules timed beside this port in the build container (tools/cpu_ref_vs_port.py)
+        rj = json.load(open(rp))
+        out["note"] = (f"reference modules vs this port on the same {rj['utterances']} utterances, {rj['threads']} threads, build container: "
+                       f"reference {rj['reference_rtfx']}x, port {rj['port_rtfx']}x real time (port/reference = {rj['port_over_reference']}); "
+                       "profiles/r03_cpu_ref_vs_port.json")
     if sweep_out:
         out["thread_sweep_rtfx"] = {str(k): v for k, v in sweep_out.items()}
     if sum(same) != len(same):
@@ -273,13 +278,79 @@ def rnnt_bias_for(model_name: str, override):
 
 
 def ragged_host(ids, frames, counts):
-    """Decoded buffers -> host lists: the blocking D2H + slicing of gigaam_amd.decoding._ragged."""
-    n = counts.cpu().tolist()
-    if n and min(n) < 0:
-        raise RuntimeError("decode reported a failed cluster hand-off (counts = -1)")
-    width = max(n) if n else 0
-    ih, fh = ids[:, :width].cpu(), frames[:, :width].cpu()
-    return [(ih[i, :c].tolist(), fh[i, :c].tolist()) for i, c in enumerate(n)]
+    """Decoded buffers -> host lists: the blocking D2H + slicing of gigaam_amd.decoding._ragged (the split-fp16 range flag
+    rides on the counts copy: engine.collect)."""
+    from gigaam_amd.engine import HipEngine
+    rows, flag = HipEngine.collect(ids, frames, counts)
+    if flag:   # the product would repeat the batch in fp32 (model._with_f32_fallback); a timed step must not do that silently
+        raise RuntimeError("split-fp16 range flag set during a bench step")
+    return rows
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n: int, argv) -> int:
+    """``python bench.py --gpus N`` with no launcher around it (WORLD_SIZE unset): start the N ranks ourselves -- one
+    process per GPU, the same environment contract torch.distributed.run provides (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT on 127.0.0.1) -- and pass rank 0's stdout through, so the caller still reads ONE JSON line.
+    Returns the exit code (first non-zero rank's)."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), GAM_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                c = procs[r].poll()
+                if c is None:
+                    continue
+                pending.discard(r)
+                if c != 0 and rc == 0:
+                    rc = c
+                    print(f"[bench] rank {r} exited with code {c}; stopping the other ranks", file=sys.stderr)
+                    for q in pending:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
+def launch_selftest(rank: int, n_ranks: int, args):
+    """--launch-selftest: the rank plumbing of this script without a GPU (gloo): rendezvous, the barrier-bracketed timed
+    region with max-over-ranks, the exchange, ONE line from rank 0.  tests/test_distributed_gloo.py runs it through the
+    same ``python bench.py --gpus 2`` entry the driver uses."""
+    if n_ranks > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=n_ranks)
+    counts = torch.tensor([rank + 1], dtype=torch.int32)
+    ids = torch.full((1, 4), rank, dtype=torch.int32)
+    barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (rank + 1))
+        _, gc, gids, _ = shard.torch_gather(None, counts, ids, ids)
+    barrier_sync()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    if rank == 0:
+        emit({"selftest": True, "n_gpus": n_ranks, "steps": args.steps, "ms_per_step": round(dt / args.steps * 1e3, 3),
+              "gathered_counts": gc.tolist(), "gathered_ids": gids[:, 0].tolist(),
+              "launcher": "bench.py self-launch" if os.environ.get("GAM_BENCH_SELF_LAUNCHED") else "external"}, n_ranks)
+    elif n_ranks > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -305,22 +376,49 @@ def main():
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the exact-fp32 re-timing (roofline_f32_exact)")
     ap.add_argument("--gemm", default="f16x3", choices=["f16x3", "f32"],
                     help="dense-contraction arithmetic: split-fp16 MFMA (fp32-equivalent, default) or exact fp32 MFMA")
+    ap.add_argument("--launch-selftest", action="store_true", help="CPU-only check of the rank plumbing (gloo); no GPU work")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: ranks share devices (rank %% device_count) and "
+                         "torch.distributed runs on gloo (RCCL refuses two ranks on one device); the line is marked INVALID")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's plain `python bench.py --gpus N`: no launcher set the rank environment, so this process becomes it
+        if not args.launch_selftest:
+            have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if have < args.gpus and not args.oversubscribe:
+                raise SystemExit(f"bench.py --gpus {args.gpus}: {have} GPU(s) visible on this box; one process per GPU needs "
+                                 f"{args.gpus} (a rehearsal with ranks sharing devices: --oversubscribe)")
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     n_ranks = int(os.environ.get("WORLD_SIZE", "1"))
+    if n_ranks != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={n_ranks}: launch {args.gpus} ranks "
+                         f"(torch.distributed.run --nproc-per-node {args.gpus}) or drop the launcher and let bench.py start them")
+    if args.launch_selftest:
+        return launch_selftest(rank, n_ranks, args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (no CPU fallback)")
     # host side of the timed region: a handful of small CPU tensor ops.  Left at the default (one OpenMP thread per
     # core) they spin on every core of the box and, under a CPU quota, get the launching thread throttled mid-batch.
     torch.set_num_threads(min(8, os.cpu_count() or 1))
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    if local_rank >= n_dev and not args.oversubscribe:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {n_dev} GPU(s) visible (one process per GPU; --oversubscribe "
+                         "for a shared-device rehearsal)")
+    shared = args.oversubscribe and n_ranks > n_dev
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
     if n_ranks > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=n_ranks, device_id=torch.device("cuda", local_rank))
-    assert n_ranks == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={n_ranks}"
-    dev = torch.device("cuda", local_rank)
+        if shared:
+            dist.init_process_group("gloo", rank=rank, world_size=n_ranks)
+            args.gather = "torch"
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=n_ranks, device_id=torch.device("cuda", dev_index))
+    dev = torch.device("cuda", dev_index)
 
     import gigaam_amd
     from gigaam_amd import synth, workloads
@@ -342,11 +440,6 @@ def main():
         feat, flen = eng.frontend(wav, wlen)
         enc, elen = eng.encode(feat, flen)
         return eng.rnnt_greedy(enc, elen, max_sym) if is_rnnt else eng.ctc_greedy(enc, elen)
-
-    def decode_batch(wav, wlen):
-        out_ = decode_dev(wav, wlen)
-        eng.range_flag()
-        return ragged_host(*out_)
 
     # ---- the step of each configuration; `audio_s` = audio seconds ALL ranks process per step
     cpu_sample = None       # (wav, wlen) on the host + global indices, for the CPU-oracle leg
@@ -379,11 +472,12 @@ def main():
                     ids = torch.cat([ids, ids.new_zeros((pad, ids.shape[1]))])
                     frames = torch.cat([frames, frames.new_zeros((pad, frames.shape[1]))])
                     counts = torch.cat([counts, counts.new_zeros((pad,))])
+                if eng.range_flag():                       # (N > 1: this rank's flag, before its rows leave for the other ranks)
+                    raise RuntimeError("split-fp16 range flag set during a bench step")
                 gi, gc, gids, gfr = gather(idx_dev, counts, ids, frames)
                 keep = gi >= 0
                 ids, frames, counts = gids[keep], gfr[keep], gc[keep]
-            eng.range_flag()                               # the shim's range check (one 4-byte D2H + sync), as in model.forward
-            return ragged_host(ids, frames, counts)        # the decoded ids end every step on the host
+            return ragged_host(ids, frames, counts)        # the decoded ids (+ the range flag at N = 1) end every step on the host
         workload = (f"{model_name} (16-layer Conformer, random-init weights), {n_global} x {seconds:g} s 16 kHz utterances "
                     f"({'%d per GPU' % args.batch if scaling == 'weak' else 'global batch split over the ranks'}), frontend + encoder + "
                     f"{'RNN-T' if is_rnnt else 'CTC'} greedy + ids to host, final gather of ids")
@@ -401,7 +495,6 @@ def main():
         def step():
             # batch n is launched before batch n-1's ids are copied back (shard.run_sharded, collect=)
             res = shard.run_sharded(batches, decode_dev, rank, n_ranks, gather, cap, my_batches=mine, collect=lambda h: ragged_host(*h))
-            eng.range_flag()
             return res if rank != 0 else [(i, f, tok.decode(i)) for i, f in res]     # detokenised like the package API
         workload = (f"{model_name} (V = 1025), {n_utts} utterances with durations U(5 s, 20 s) sorted into 32-utterance batches "
                     f"dealt to {n_ranks} rank(s) ({len(mine)} batches on rank 0), frontend + encoder + RNN-T greedy + ids to host + "
@@ -420,6 +513,14 @@ def main():
         tok = model.decoding.tokenizer
 
         feeder = BatchFeeder(my_segs, fr_bs, dev) if my_segs else []       # pinned staging buffers: allocated once
+        last5 = {}
+        if rank == 0:
+            # CPU-oracle leg: the longest chunk (the T' <= 751 case no other configuration reaches) + three spread over the file
+            from gigaam_amd.feeder import collate
+            order = sorted(range(len(segs)), key=lambda i: -int(segs[i].shape[0]))
+            pick = [order[0]] + [i for i in (0, len(segs) // 2, len(segs) - 1) if i != order[0]][:3]
+            w5, l5 = collate([segs[i] for i in pick])
+            cpu_sample = (w5, l5, pick)
 
         trace = os.environ.get("GAM_BENCH_TRACE")   # debug: host timestamps per batch (ms since the step began)
 
@@ -439,8 +540,8 @@ def main():
                 print("[trace] (staged_at, launch_ms, collect_prev_ms, shape):", marks, file=sys.stderr)
             if pending is not None:
                 rows += [(my_idx[len(rows) + k], i, f) for k, (i, f) in enumerate(ragged_host(*pending))]
-            eng.range_flag()
             res = shard.unpack_results(*gather(*shard.pack_results(rows, per_rank, cap)), len(segs))
+            last5["res"] = res
             return res if rank != 0 else [(tok.decode(i), bounds[k]) for k, (i, f) in enumerate(res)]
         workload = (f"{model_name} longform: {args.longform_seconds} s of audio -> {len(segs)} chunks (reference packer 22/15/30/0.2 s) -> "
                     f"batches of {fr_bs} dealt round-robin to {n_ranks} rank(s), streamed from host memory through the pinned "
@@ -534,6 +635,8 @@ def main():
         line["rnnt_blank_bias"] = bias
     if args.layers >= 0:
         line["INVALID"] = "debug run with --layers"
+    if shared:
+        line["INVALID"] = f"rehearsal: {n_ranks} ranks share {n_dev} GPU(s) (--oversubscribe), exchange over gloo -- not a scaling measurement"
     if prof is not None:
         if args.gemm == "f32":
             kern, peak, peak_note = "gam_gemm_f32_kernel (v_mfma_f32_32x32x2_f32; plain + implicit-GEMM conv)", FP32_MFMA_PEAK_TFLOPS, \
@@ -602,8 +705,10 @@ def main():
             w_h, l_h, gidx = cpu_sample
             if cfgno in (1, 2, 3):
                 gpu_dec = decoded_mine
-            else:
+            elif cfgno == 4:
                 gpu_dec = [(out[g][0], out[g][1]) for g in gidx]
+            else:
+                gpu_dec = [tuple(last5["res"][g]) for g in gidx]
             line["cpu_baseline"] = cpu_baseline(ckpt, w_h, l_h, min(n_cpu, w_h.shape[0]), gpu_dec, sweep=(cfgno == 2))
         except Exception as e:  # the bench line must still print
             line["cpu_baseline"] = {"error": repr(e)}

@@ -54,6 +54,7 @@ SIGNATURES = {
     "gam_set_gemm_mode": (C.c_int, [_P, C.c_int]),
     "gam_get_gemm_mode": (C.c_int, [_P]),
     "gam_range_flag": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
+    "gam_range_flag_fetch": (C.c_int, [_P, _P, _P]),
     "gam_op_gemm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "gam_op_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "gam_profile_enable": (C.c_int, [_P, C.c_int]),

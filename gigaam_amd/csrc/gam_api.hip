@@ -101,6 +101,8 @@ struct gam_handle {
   int use_range = 1;            // GAM_RANGE=0: no range guard on the unscaled operands (A/B switch)
   int ncu = 256;                // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   int rnnt_cluster = -1;        // GAM_RNNT_CLUSTER: 0 = one workgroup per utterance, N = force N per utterance, -1 = auto
+  int rnnt_coop = 1;            // GAM_RNNT_COOP=0: plain instead of cooperative launch of the cluster kernel
+  int rnnt_force_timeout = 0;   // GAM_RNNT_FORCE_TIMEOUT=1 (test hook): odd utterances' clusters report a failed hand-off
   DevBuf rnnt_x;                // hand-off granules + status word of the cluster kernel
 
   // workspace (grow-only)
@@ -385,9 +387,13 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   if (const char* e = getenv("GAM_SPLITK")) h->use_splitk = atoi(e);
   if (const char* e = getenv("GAM_GRAPH")) h->use_graph = atoi(e);
   if (const char* e = getenv("GAM_RNNT_CLUSTER")) h->rnnt_cluster = atoi(e);
+  if (const char* e = getenv("GAM_RNNT_COOP")) h->rnnt_coop = atoi(e);
+  if (const char* e = getenv("GAM_RNNT_FORCE_TIMEOUT")) h->rnnt_force_timeout = atoi(e);
   {
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && n > 0) h->ncu = n;
+    int co = 0;
+    if (hipDeviceGetAttribute(&co, hipDeviceAttributeCooperativeLaunch, device_id) != hipSuccess || co == 0) h->rnnt_coop = 0;
   }
   if (const char* e = getenv("GAM_ROWSCALE")) h->use_rowscale = atoi(e);
   if (const char* e = getenv("GAM_RANGE")) h->use_range = atoi(e);
@@ -878,6 +884,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       a.feat = feat; a.img = h->img.p; a.w = h->c1_w; a.bias = h->c1_b; a.len0 = len0; a.len1 = len1;
       a.B = B; a.T = (int)T; a.F = F; a.Ta = Ta; a.FP = FP; a.C = C; a.T1 = T1;
       a.img_split = sp && C % 32 == 0;
+      a.range_flag = h->use_range ? h->range_flag : nullptr;
       ProfScope ps(h, s, GAM_PF_STEM, (double)B * 2 * Ta * FP * C * 4.0);
       hipLaunchKernelGGL(gam_conv2d1_kernel, dim3(2 * Ta, B), dim3(256), 0, s, a);
       HIPCHK(h, hipGetLastError());
@@ -957,10 +964,10 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       if (int r = layernorm(h, s, a, rel ? 0 : 1)) return r;
       // rotary: q,k project the rotated copy, v the plain one; rel_pos: all three project y
       GamGemmArgs gq = gemm_args(rel ? h->y.p : h->yr.p, D, L.wqk, L.bqk, h->qk.p, 2 * D, N, 2 * D, D);
-      sp_a(gq); gq.a_rs = rs;
+      sp_a(gq); gq.a_rs = rs; gq.c_guard = 1;   // q, k and v are split to fp16 unscaled by the attention kernel
       if (int r = gemm(h, s, gq, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wqk)) return r;
       GamGemmArgs gv = gemm_args(h->y.p, D, L.wv, L.bv, h->vbuf.p, D, N, D, D);
-      sp_a(gv); gv.a_rs = rs;
+      sp_a(gv); gv.a_rs = rs; gv.c_guard = 1;
       if (int r = gemm(h, s, gv, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wv)) return r;
       if (rel) {  // P = linear_pos(pos_emb) for relative positions -(T'-1) .. T'-1 (no bias)
         const float* pe0 = h->rel_pe + (size_t)(c.pos_emb_max_len - 1 - (Tv - 1)) * D;
@@ -1163,11 +1170,31 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
   GamGemmArgs g = gemm_args(h->tok.p, D, h->jn_enc_w, h->jn_enc_b, h->encp.p, JH, (int)(B * Tp), JH, D);
   if (int r = gemm(h, s, g, GAM_ACT_NONE, GAM_PF_DECODE)) return r;
   GamRnntArgs a;
+  memset(&a, 0, sizeof a);
   a.encp = h->encp.p; a.enc_len = enc_len; a.gate_tab = h->lstm_tab; a.whh_t = h->lstm_whh_t; a.wpred_t = h->jn_pred_t;
   a.bpred = h->jn_pred_b; a.wout = h->jn_out_w; a.bout = h->jn_out_b; a.ids = ids; a.frames = frames; a.counts = counts;
   a.dump = logits_dump; a.dump_count = dump_count; a.B = B; a.Tp = (int)Tp; a.V = c.num_classes; a.H = c.pred_hidden; a.JH = JH;
   a.max_symbols = max_symbols; a.cap = (int)Tp * max_symbols; a.dump_cap = logits_dump ? dump_cap : 0;
   ProfScope ps(h, s, GAM_PF_DECODE, 0.0);
+  // One workgroup per utterance (gam_decode.h): the whole decode when the cluster kernel does not take the shape
+  // (GAM_RNNT_CLUSTER=0, a refused cooperative launch), and -- with only_failed -- the REPAIR pass behind every cluster
+  // launch: a workgroup of it returns at once unless the cluster kernel left its utterance at counts[b] = -1 (a hand-off
+  // timed out because a member was not resident: GPU shared with another process / stream, CU-masked partition).  The
+  // caller therefore always gets the reference's ids back, without a host round trip and without an exception.
+  auto launch_single = [&](int only_failed) -> int {
+    GamRnntArgs f = a;
+    f.only_failed = only_failed;
+    f.wout_in_lds = gam_rnnt_smem(f.H, f.JH, f.V, 1) <= 96 * 1024 ? 1 : 0;
+    const size_t sm1 = gam_rnnt_smem(f.H, f.JH, f.V, f.wout_in_lds);
+    static std::atomic<unsigned long long> attr5{0}, attr8{0};
+    HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_rnnt_greedy_kernel<5>), 160 * 1024, attr5));
+    HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_rnnt_greedy_kernel<8>), 160 * 1024, attr8));
+    if (sm1 > 160 * 1024) return fail(h, -1, "RNN-T head too large for the greedy kernel's LDS window");
+    if (4 * f.H <= 256 * 5) hipLaunchKernelGGL(gam_rnnt_greedy_kernel<5>, dim3(B), dim3(256), sm1, s, f);
+    else hipLaunchKernelGGL(gam_rnnt_greedy_kernel<8>, dim3(B), dim3(256), sm1, s, f);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+  };
   // Cluster decode (gam_decode_cluster.h): C workgroups per utterance, grid <= one workgroup per CU.
   // (8 utterance columns, one per XCD; C members of a cluster share an XCD.)
   {
@@ -1179,7 +1206,9 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
     if (h->rnnt_cluster >= 0) C = h->rnnt_cluster < C ? h->rnnt_cluster : C;
     if (C >= 1 && JH % 16 == 0 && a.H % 4 == 0) {   // (JH % 16: MFMA k-steps and the LDS-DMA window)
       GamRnntClusterArgs ca;
+      memset(&ca, 0, sizeof ca);
       ca.a = a; ca.whh_q = h->lstm_whh_q; ca.wpred_q = h->jn_pred_q; ca.C = C;
+      ca.force_dead = h->rnnt_force_timeout;
       const int nI = gam_cdiv(a.H, C), need = gam_cdiv(4 * nI, 256);
       const int nr = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 3 ? 3 : (need <= 5 ? 5 : 8)));
       const int nV = gam_cdiv(gam_cdiv(a.V, C), 16) * 16;
@@ -1193,59 +1222,47 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
         ca.xbuf = reinterpret_cast<unsigned long long*>(h->rnnt_x.p);
         ca.status = reinterpret_cast<int*>(h->rnnt_x.p + xg * 2);
         const dim3 grid(8 * nu8 * C);
-        static std::atomic<unsigned long long> at1{0}, at2{0}, at3{0}, at5{0}, at8{0};
-#define GAM_RC_LAUNCH(NRV, AT)                                                                                             \
-  {                                                                                                                        \
-    HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<NRV>), 160 * 1024, AT));               \
-    hipLaunchKernelGGL(gam_rnnt_cluster_kernel<NRV>, grid, dim3(256), sm, s, ca);                                          \
-  }
-        static std::atomic<unsigned long long> at1r{0};
-        if (nr == 1 && a.H == 320 && JH == 320) {   // W_hh rows register-resident (gam_decode_cluster.h RESQ)
-          HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<1, 80>), 160 * 1024, at1r));
-          hipLaunchKernelGGL((gam_rnnt_cluster_kernel<1, 80>), grid, dim3(256), sm, s, ca);
-          HIPCHK(h, hipGetLastError());
-          if (GAM_RC_TIMING && getenv("GAM_RNNT_TIMING")) {
-            int st[16];
-            HIPCHK(h, hipStreamSynchronize(s));
-            HIPCHK(h, hipMemcpy(st, ca.status, sizeof st, hipMemcpyDeviceToHost));
-            fprintf(stderr, "[gam] rnnt cluster C=%d (resident) utt0: rounds %d; us: gates %.0f xH %.0f pred %.0f xP %.0f z %.0f joint %.0f xA %.0f comb %.0f ctrl %.0f\n", C,
-                    st[T_ROUNDS], st[T_GATES] / 100.0, st[T_XH] / 100.0, st[T_PRED] / 100.0, st[T_XP] / 100.0, st[T_Z] / 100.0, st[T_JOINT] / 100.0,
-                    st[T_XA] / 100.0, st[T_COMB] / 100.0, st[T_CTRL] / 100.0);
-          }
-          return 0;
+        // Cooperative launch: the runtime REFUSES a grid that cannot be co-resident on this device (occupancy x CUs)
+        // instead of letting resident members spin on absent ones; what it cannot see (CUs held by another queue) is
+        // what the bounded spins + the repair pass below are for.
+        const bool coop = h->rnnt_coop != 0;
+        const void* kern = nullptr;
+        static std::atomic<unsigned long long> at1{0}, at2{0}, at3{0}, at5{0}, at8{0}, at1r{0};
+        std::atomic<unsigned long long>* at = nullptr;
+        const bool resident = nr == 1 && a.H == 320 && JH == 320;   // W_hh rows register-resident (gam_decode_cluster.h RESQ)
+        if (resident) { kern = reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<1, 80>); at = &at1r; }
+        else switch (nr) {
+          case 1: kern = reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<1>); at = &at1; break;
+          case 2: kern = reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<2>); at = &at2; break;
+          case 3: kern = reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<3>); at = &at3; break;
+          case 5: kern = reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<5>); at = &at5; break;
+          default: kern = reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<8>); at = &at8; break;
         }
-        switch (nr) {
-          case 1: GAM_RC_LAUNCH(1, at1); break;
-          case 2: GAM_RC_LAUNCH(2, at2); break;
-          case 3: GAM_RC_LAUNCH(3, at3); break;
-          case 5: GAM_RC_LAUNCH(5, at5); break;
-          default: GAM_RC_LAUNCH(8, at8); break;
+        HIPCHK(h, gam_set_max_lds(kern, 160 * 1024, *at));
+        void* kargs[] = {&ca};
+        hipError_t le = coop ? hipLaunchCooperativeKernel(kern, grid, dim3(256), kargs, (unsigned)sm, s)
+                             : hipLaunchKernel(kern, grid, dim3(256), kargs, sm, s);
+        if (le != hipSuccess) {
+          (void)hipGetLastError();
+          static std::atomic<int> warned{0};
+          if (!warned.exchange(1))
+            fprintf(stderr, "[gam] RNN-T cluster decode: %s launch of %u workgroups refused (%s); decoding with one workgroup per utterance\n",
+                    coop ? "cooperative" : "plain", grid.x, hipGetErrorString(le));
+          return launch_single(0);
         }
-#undef GAM_RC_LAUNCH
-        HIPCHK(h, hipGetLastError());
         if (GAM_RC_TIMING && getenv("GAM_RNNT_TIMING")) {
           int st[16];
           HIPCHK(h, hipStreamSynchronize(s));
           HIPCHK(h, hipMemcpy(st, ca.status, sizeof st, hipMemcpyDeviceToHost));
-          fprintf(stderr, "[gam] rnnt cluster C=%d utt0: rounds %d; us: gates %.0f xH %.0f pred %.0f xP %.0f z %.0f joint %.0f xA %.0f comb %.0f ctrl %.0f\n", C,
-                  st[T_ROUNDS], st[T_GATES] / 100.0, st[T_XH] / 100.0, st[T_PRED] / 100.0, st[T_XP] / 100.0, st[T_Z] / 100.0, st[T_JOINT] / 100.0,
-                  st[T_XA] / 100.0, st[T_COMB] / 100.0, st[T_CTRL] / 100.0);
+          fprintf(stderr, "[gam] rnnt cluster C=%d%s utt0: rounds %d; us: gates %.0f xH %.0f pred %.0f xP %.0f z %.0f joint %.0f xA %.0f comb %.0f ctrl %.0f\n", C,
+                  resident ? " (resident)" : "", st[T_ROUNDS], st[T_GATES] / 100.0, st[T_XH] / 100.0, st[T_PRED] / 100.0, st[T_XP] / 100.0, st[T_Z] / 100.0,
+                  st[T_JOINT] / 100.0, st[T_XA] / 100.0, st[T_COMB] / 100.0, st[T_CTRL] / 100.0);
         }
-        return 0;
+        return launch_single(1);   // repair pass: no-op workgroups unless a cluster gave up
       }
     }
   }
-  // fallback: one workgroup per utterance (GAM_RNNT_CLUSTER=0, or shapes the cluster kernel does not take)
-  a.wout_in_lds = gam_rnnt_smem(a.H, a.JH, a.V, 1) <= 96 * 1024 ? 1 : 0;
-  const size_t sm = gam_rnnt_smem(a.H, a.JH, a.V, a.wout_in_lds);
-  static std::atomic<unsigned long long> attr5{0}, attr8{0};
-  HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_rnnt_greedy_kernel<5>), 160 * 1024, attr5));
-  HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_rnnt_greedy_kernel<8>), 160 * 1024, attr8));
-  if (sm > 160 * 1024) return fail(h, -1, "RNN-T head too large for the greedy kernel's LDS window");
-  if (4 * a.H <= 256 * 5) hipLaunchKernelGGL(gam_rnnt_greedy_kernel<5>, dim3(B), dim3(256), sm, s, a);
-  else hipLaunchKernelGGL(gam_rnnt_greedy_kernel<8>, dim3(B), dim3(256), sm, s, a);
-  HIPCHK(h, hipGetLastError());
-  return 0;
+  return launch_single(0);
 }
 
 int gam_emo_probs(gam_handle* h, const float* encoded, const int32_t* enc_len, int B, int64_t Tp, float* probs,
@@ -1343,6 +1360,16 @@ int gam_range_flag(gam_handle* h, int* flag_host, void* stream) {
   HIPCHK(h, hipMemcpyAsync(flag_host, h->range_flag, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipMemsetAsync(h->range_flag, 0, sizeof(int), s));
   HIPCHK(h, hipStreamSynchronize(s));
+  return 0;
+}
+
+int gam_range_flag_fetch(gam_handle* h, int32_t* flag_dev, void* stream) {
+  if (!h || !flag_dev) return -1;
+  if (!h->finalized) return fail(h, -1, "gam_range_flag_fetch before gam_finalize");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  HIPCHK(h, hipMemcpyAsync(flag_dev, h->range_flag, sizeof(int), hipMemcpyDeviceToDevice, s));
+  HIPCHK(h, hipMemsetAsync(h->range_flag, 0, sizeof(int), s));
   return 0;
 }
 

@@ -69,9 +69,12 @@ __global__ __launch_bounds__(512, 4) void gam_convmod_bn_kernel(GamConvModArgs a
   for (int u = 0; u < NLD; ++u) {
     const int rr = rg + NRG * u;
     const int t = t0 - PAD + rr;
-    const float m = (t >= 0 && t < klen) ? 1.0f : 0.0f;   // a select, not a branch: padded frames enter the taps as 0
-    tile[rr * 16 + q] = (f32x4){m * ua[u].x * gam_sigmoid(ub[u].x), m * ua[u].y * gam_sigmoid(ub[u].y),
-                                m * ua[u].z * gam_sigmoid(ub[u].z), m * ua[u].w * gam_sigmoid(ub[u].w)};
+    // a true select (v_cndmask, no branch), like the reference's masked_fill: padded / don't-care frames enter the taps as
+    // exact zeros even when the grow-only workspace holds inf or NaN there (0 * NaN would leak into the valid frames)
+    const bool live = t >= 0 && t < klen;
+    const f32x4 glu = (f32x4){ua[u].x * gam_sigmoid(ub[u].x), ua[u].y * gam_sigmoid(ub[u].y),
+                              ua[u].z * gam_sigmoid(ub[u].z), ua[u].w * gam_sigmoid(ub[u].w)};
+    tile[rr * 16 + q] = live ? glu : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
   // The taps run over a register window of OUT + KS - 1 tile rows.  With all four channels of the lane in one
@@ -263,9 +266,10 @@ __global__ __launch_bounds__(256) void gam_convmod_ln4_kernel(GamConvModArgs a) 
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {   // GLU, padded frames enter the taps as 0 (a select, not a branch)
     const int t = t0 - PAD + r;
-    const float m = (t >= 0 && t < klen) ? 1.0f : 0.0f;
-    ua[r] = (f32x4){m * ua[r].x * gam_sigmoid(ub[r].x), m * ua[r].y * gam_sigmoid(ub[r].y), m * ua[r].z * gam_sigmoid(ub[r].z),
-                    m * ua[r].w * gam_sigmoid(ub[r].w)};
+    const bool live = t >= 0 && t < klen;   // (true select: 0 * NaN from a don't-care frame must not reach valid frames)
+    const f32x4 glu = (f32x4){ua[r].x * gam_sigmoid(ub[r].x), ua[r].y * gam_sigmoid(ub[r].y), ua[r].z * gam_sigmoid(ub[r].z),
+                              ua[r].w * gam_sigmoid(ub[r].w)};
+    ua[r] = live ? glu : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   f32x4 y[TT];
 #pragma unroll

@@ -108,6 +108,7 @@ struct GamRnntArgs {
   float* dump; int* dump_count;         // optional [B, dump_cap, V] log-probs of every joint call
   int B, Tp, V, H, JH, max_symbols, cap, dump_cap;
   int wout_in_lds;       // set by the launcher: W_out (V x JH fp32) is cached in LDS
+  int only_failed;       // repair pass behind the cluster kernel: decode only the utterances it left at counts[b] < 0
 };
 
 #define GAM_RNNT_MAXH 512
@@ -143,6 +144,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_greedy_kernel(GamRnntArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg4 = lane >> 4;
   const int b = blockIdx.x;
+  if (a.only_failed && a.counts[b] >= 0) return;   // (block-uniform) the cluster kernel finished this utterance
   int len = a.enc_len[b];
   len = len < 0 ? 0 : (len > a.Tp ? a.Tp : len);
 

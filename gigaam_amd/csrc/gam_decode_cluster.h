@@ -39,6 +39,7 @@ struct GamRnntClusterArgs {
   int C;                     // workgroups per utterance
   int wout_slice_in_lds;     // this member's class slice of W_out is cached in LDS
   int wpred_slice_in_lds;    // this member's rows of W_pred are cached in LDS ([H/4][nP][4]): the step's pp no longer waits on L2
+  int force_dead;            // test hook (GAM_RNNT_FORCE_TIMEOUT=1): odd utterances report a failed hand-off without decoding
 };
 
 #define GAM_RC_WIN 16
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
   bool need_pred = true;
   unsigned xc = 0;     // exchange counter = tag
   int par_h = 0, par_p = 0, par_a = 0;
-  bool dead = false;
+  bool dead = g.force_dead && (b & 1);
 
 #if GAM_RC_TIMING
   long long tacc[12] = {0}, tlast = wall_clock64();

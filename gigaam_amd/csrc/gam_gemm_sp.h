@@ -314,11 +314,11 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
       if (masked) v = (f32x4){0.f, 0.f, 0.f, 0.f};
       v = v * g.alpha;
       if (g.R != nullptr) v += *reinterpret_cast<const f32x4*>(g.R + orow * g.ldr + ecol);
+      if (g.c_guard) gam_range_note(g.range_flag, v.x, v.y, v.z, v.w);
       if (g.c_split) {
         _Float16* cp = reinterpret_cast<_Float16*>(g.C) + orow * (2 * g.ldc) + (ecol >> 5) * 64 + (ecol & 31);
         gam_half4 hi, lo;
         gam_split4(v, hi, lo);
-        if (g.c_guard) gam_range_note(g.range_flag, v.x, v.y, v.z, v.w);
         *reinterpret_cast<gam_half4*>(cp) = hi;
         *reinterpret_cast<gam_half4*>(cp + 32) = lo;
       } else {

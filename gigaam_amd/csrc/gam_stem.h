@@ -41,6 +41,7 @@ struct GamConv1Args {
   const int* len1;     // valid output frames of this stage
   int B, T, F, Ta, FP, C, T1;
   int img_split;       // channels of a pixel in the sp32 GEMM-operand layout (C % 32 == 0)
+  int* range_flag;     // img_split: a pixel beyond fp16's range sets it (gam_common.h gam_range_note); may be null
 };
 
 __global__ __launch_bounds__(256) void gam_conv2d1_kernel(GamConv1Args a) {
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256) void gam_conv2d1_kernel(GamConv1Args a) {
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) acc = fmaf(w[kh * 3 + kw], xin[kh][fb + kw], acc);
+      if (a.img_split) gam_range_note(a.range_flag, acc, 0.f, 0.f, 0.f);   // the image feeds Conv2d#2 unscaled
       gam_store1(out, (size_t)q * a.C, c, fmaxf(acc, 0.f), a.img_split);
     }
   }

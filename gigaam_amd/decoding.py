@@ -39,16 +39,20 @@ class Tokenizer:
         return self.vocab[token_id] if self.charwise else self.model.IdToPiece(token_id)
 
 
+class RangeOverflow(RuntimeError):
+    """Raised by ``finish`` when the batch it collects set the split-fp16 range flag (include/gigaam_hip.h,
+    gam_range_flag): an activation left fp16's range somewhere before this decode, so its ids are not to be trusted.
+    The model shim catches it and repeats the work under GAM_GEMM_F32 (model.py); a caller that drives the decoders
+    directly sees it as an error, never as silently wrong ids."""
+
+
 def _ragged(ids: Tensor, frames: Tensor, counts: Tensor) -> List[Tuple[List[int], List[int]]]:
-    n = counts.cpu().tolist()
-    if n and min(n) < 0:   # gam_decode_cluster.h: a hand-off inside a decode cluster timed out (counts[b] = -1)
-        from ._lib import GigaAMHipError
-        raise GigaAMHipError("RNN-T cluster decode: a workgroup hand-off timed out (GPU shared with another job?); "
-                             "set GAM_RNNT_CLUSTER=0 to decode with one workgroup per utterance")
-    width = max(n) if n else 0
-    ids_h = ids[:, :width].cpu()
-    fr_h = frames[:, :width].cpu()
-    return [(ids_h[i, :c].tolist(), fr_h[i, :c].tolist()) for i, c in enumerate(n)]
+    """Device buffers of decode_device -> host lists (one D2H for counts + range flag, one for ids/frames)."""
+    from .engine import HipEngine
+    rows, flag = HipEngine.collect(ids, frames, counts)
+    if flag:
+        raise RangeOverflow("activation beyond the split-fp16 GEMM range (repeat under GAM_GEMM_F32)")
+    return rows
 
 
 class CTCGreedyDecoding:

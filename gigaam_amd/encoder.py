@@ -65,8 +65,12 @@ class ConformerEncoder(_EngineModule):
     def _cfg_trees(self):
         return None, self.cfg, None
 
+    def forward_f32(self, audio_signal: Tensor, length: Tensor) -> Tuple[Tensor, Tensor]:
+        """The kernels' own output: fp32 whatever the module's storage dtype is (what the heads of this package consume)."""
+        return self.engine.encode(audio_signal, length)
+
     def forward(self, audio_signal: Tensor, length: Tensor) -> Tuple[Tensor, Tensor]:
-        enc, elen = self.engine.encode(audio_signal, length)
+        enc, elen = self.forward_f32(audio_signal, length)
         if self._anchor.dtype != torch.float32:   # .half()-ed encoder (fp16_encoder=True): fp16 at the boundary
             enc = enc.to(self._anchor.dtype)
         return enc, elen

@@ -148,6 +148,32 @@ class HipEngine:
             self._check(self.lib.gam_range_flag(self._h, C.byref(out), self._stream()), "gam_range_flag")
         return bool(out.value)
 
+    def _counts_with_flag(self, b: int) -> Tuple[Tensor, Tensor]:
+        """counts i32 [b] as a view of a [b + 1] buffer whose last element receives the range flag
+        (gam_range_flag_fetch) -- ``collect`` then brings both to the host in ONE copy."""
+        ext = torch.empty((b + 1,), dtype=torch.int32, device=self.device)
+        counts = ext[:b]
+        counts._gam_ext = ext          # (plain attribute: keeps the buffer alive and findable from the view)
+        return counts, ext
+
+    def _fetch_flag(self, ext: Tensor) -> None:
+        rc = self.lib.gam_range_flag_fetch(self._h, C.c_void_p(ext.data_ptr() + 4 * (ext.numel() - 1)), self._stream())
+        self._check(rc, "gam_range_flag_fetch")
+
+    @staticmethod
+    def collect(ids: Tensor, frames: Tensor, counts: Tensor):
+        """Decoded device buffers -> ([(ids, frames)] host lists, range_flag).  One blocking D2H for the counts AND the
+        split-fp16 range flag accumulated up to this decode (when ``counts`` came from ctc_greedy / rnnt_greedy), one
+        for the used part of ids/frames."""
+        ext = getattr(counts, "_gam_ext", None)
+        n = (ext if ext is not None else counts).cpu().tolist()
+        flag = bool(n.pop()) if ext is not None else False
+        if n and min(n) < 0:   # cannot happen: gam_rnnt_greedy repairs failed clusters itself (gam_api.hip launch_single)
+            raise GigaAMHipError("RNN-T decode left an utterance undecoded (counts = -1)")
+        width = max(n) if n else 0
+        ids_h, fr_h = ids[:, :width].cpu(), frames[:, :width].cpu()
+        return [(ids_h[i, :c].tolist(), fr_h[i, :c].tolist()) for i, c in enumerate(n)], flag
+
     def feat_frames(self, n_samples: int) -> int:
         return int(self.lib.gam_feat_frames(self._h, n_samples))
 
@@ -213,11 +239,12 @@ class HipEngine:
         b, _, tp = encoded.shape
         ids = torch.empty((b, tp), dtype=torch.int32, device=self.device)
         frames = torch.empty((b, tp), dtype=torch.int32, device=self.device)
-        counts = torch.empty((b,), dtype=torch.int32, device=self.device)
+        counts, ext = self._counts_with_flag(b)
         with torch.cuda.device(self.device):
             rc = self.lib.gam_ctc_greedy(self._h, _ptr(encoded), _ptr(enc_len), b, tp, _ptr(ids), _ptr(frames),
                                          _ptr(counts), self._stream())
-        self._check(rc, "gam_ctc_greedy")
+            self._check(rc, "gam_ctc_greedy")
+            self._fetch_flag(ext)
         return ids, frames, counts
 
     def rnnt_greedy(self, encoded: Tensor, enc_len: Tensor, max_symbols: int, dump_cap: int = 0):
@@ -227,7 +254,7 @@ class HipEngine:
         cap = tp * max_symbols
         ids = torch.empty((b, cap), dtype=torch.int32, device=self.device)
         frames = torch.empty((b, cap), dtype=torch.int32, device=self.device)
-        counts = torch.empty((b,), dtype=torch.int32, device=self.device)
+        counts, ext = self._counts_with_flag(b)
         dump = dcount = None
         if dump_cap > 0:
             dump = torch.zeros((b, dump_cap, self.cfg.num_classes), dtype=torch.float32, device=self.device)
@@ -235,7 +262,8 @@ class HipEngine:
         with torch.cuda.device(self.device):
             rc = self.lib.gam_rnnt_greedy(self._h, _ptr(encoded), _ptr(enc_len), b, tp, max_symbols, _ptr(ids),
                                           _ptr(frames), _ptr(counts), _ptr(dump), _ptr(dcount), dump_cap, self._stream())
-        self._check(rc, "gam_rnnt_greedy")
+            self._check(rc, "gam_rnnt_greedy")
+            self._fetch_flag(ext)
         if dump_cap > 0:
             return ids, frames, counts, dump, dcount
         return ids, frames, counts

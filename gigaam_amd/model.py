@@ -38,9 +38,14 @@ def _node(cfg: Any, key: str) -> Any:
 
 
 def _plain(x: Any) -> Any:
-    if isinstance(x, Mapping):
-        return {k: _plain(v) for k, v in x.items()}
-    if isinstance(x, (list, tuple)) or type(x).__name__ == "ListConfig":
+    """A cfg node as plain dict / list / scalar.  The reference's checkpoints hold omegaconf containers
+    (``DictConfig`` is a ``MutableMapping``, ``ListConfig`` a ``Sequence``, both also attribute-style); anything with
+    the mapping or sequence PROTOCOL is accepted, by interface, not by class name."""
+    if isinstance(x, Mapping) or (hasattr(x, "keys") and hasattr(x, "__getitem__")):
+        return {k: _plain(x[k]) for k in x.keys()}
+    if isinstance(x, (str, bytes)):
+        return x
+    if isinstance(x, Sequence):
         return [_plain(v) for v in x]
     return x
 
@@ -92,22 +97,50 @@ class GigaAM(nn.Module):
 
     def forward(self, features: Tensor, feature_lengths: Tensor) -> Tuple[Tensor, Tensor]:
         """wav [B,L], len [B] -> encoded [B,d_model,T'], len i32 [B]  (model.py:27-37;
-        the reference wraps the encoder in fp16 autocast on GPU, this path stays fp32)."""
+        the reference wraps the encoder in fp16 autocast on GPU, this path stays fp32).  The public call checks the
+        split-fp16 range flag itself (one 4-byte D2H + sync: the caller is about to read the tensor anyway); the
+        transcribe paths read the flag together with the decode counts instead (``_encode`` + decoding.finish)."""
         features, feature_lengths = self.preprocessor(features, feature_lengths)
         out = self.encoder(features, feature_lengths)
         eng = getattr(self.encoder, "engine", None)
         if self._check_range and eng is not None and eng.gemm_mode == "f16x3" and eng.range_flag():
             # an activation outside fp16's range reached a split-fp16 GEMM operand (include/gigaam_hip.h,
             # gam_range_flag): the batch is repeated on the exact-fp32 MFMA path, which has no such limit
-            import warnings
-            warnings.warn("gigaam_amd: activation beyond the split-fp16 GEMM range; this batch was recomputed with "
-                          "GAM_GEMM_F32 (set GAM_GEMM_MODE=f32 to use that path throughout)", RuntimeWarning, stacklevel=2)
+            self._warn_range("this batch was")
             eng.set_gemm_mode("f32")
             try:
                 out = self.encoder(features, feature_lengths)
             finally:
                 eng.set_gemm_mode("f16x3")
         return out
+
+    @staticmethod
+    def _warn_range(what: str) -> None:
+        import warnings
+        warnings.warn(f"gigaam_amd: activation beyond the split-fp16 GEMM range; {what} recomputed with "
+                      "GAM_GEMM_F32 (set GAM_GEMM_MODE=f32 to use that path throughout)", RuntimeWarning, stacklevel=3)
+
+    def _encode(self, wav: Tensor, lengths: Tensor) -> Tuple[Tensor, Tensor]:
+        """Internal twin of ``forward`` for the transcribe paths: fp32 in, fp32 out whatever ``fp16_encoder`` says (the
+        fp16 storage contract of reference __init__.py:188-189 applies to what ``forward`` / ``embed_audio`` RETURN, not
+        to what the head consumes here), no host sync and no range check -- the caller reads the flag with the counts."""
+        feat, flen = self.preprocessor(wav.to(torch.float32), lengths)
+        return self.encoder.forward_f32(feat, flen)
+
+    def _with_f32_fallback(self, fn: Callable[[], Any], what: str) -> Any:
+        """Run ``fn``; if the decode it collects reports the range flag (decoding.RangeOverflow), warn and run it again
+        under GAM_GEMM_F32."""
+        from .decoding import RangeOverflow
+        try:
+            return fn()
+        except RangeOverflow:
+            eng = self.encoder.engine
+            self._warn_range(what)
+            eng.set_gemm_mode("f32")
+            try:
+                return fn()
+            finally:
+                eng.set_gemm_mode("f16x3")
 
     @property
     def _device(self) -> torch.device:
@@ -128,6 +161,25 @@ class GigaAM(nn.Module):
         wav, length = self.prepare_wav(wav_file)
         return self.forward(wav, length)
 
+    def _prepare_wav_f32(self, wav_file: str) -> Tuple[Tensor, Tensor]:
+        """``prepare_wav`` without the cast to ``_dtype``: the transcribe paths feed the fp32 frontend fp32 samples
+        (PCM16 / 32768 is exact in fp32; through fp16 it would keep 11 bits)."""
+        wav = load_audio(wav_file).to(self._device).unsqueeze(0)
+        return wav, torch.full([1], wav.shape[-1], device=self._device)
+
+    def _encode_checked(self, wav: Tensor, lengths: Tensor) -> Tuple[Tensor, Tensor]:
+        """``_encode`` + the blocking range check of ``forward`` (for heads that bring no counts to the host)."""
+        out = self._encode(wav, lengths)
+        eng = self.encoder.engine
+        if self._check_range and eng.gemm_mode == "f16x3" and eng.range_flag():
+            self._warn_range("this batch was")
+            eng.set_gemm_mode("f32")
+            try:
+                out = self._encode(wav, lengths)
+            finally:
+                eng.set_gemm_mode("f16x3")
+        return out
+
 
 class GigaAMEmo(GigaAM):
     """Emotion recognition model (reference gigaam/model.py:262-285): encoder + time pooling +
@@ -142,8 +194,8 @@ class GigaAMEmo(GigaAM):
         return _node(self.cfg, "head")
 
     def get_probs(self, wav_file: str) -> Dict[str, float]:
-        wav, length = self.prepare_wav(wav_file)
-        encoded, _ = self.forward(wav, length)
+        wav, length = self._prepare_wav_f32(wav_file)
+        encoded, _ = self._encode_checked(wav, length)
         # the reference pools over the whole T' axis of its single, unpadded file (model.py:278-280)
         probs = self.head.probs(encoded)[0].tolist()
         names = self.id2name
@@ -152,7 +204,7 @@ class GigaAMEmo(GigaAM):
     def get_probs_batch(self, wav: Tensor, lengths: Tensor) -> Tensor:
         """Batched variant: wav [B,L], lengths [B] -> probabilities [B,n_classes]; the mean runs over each
         utterance's valid encoder frames."""
-        encoded, enc_len = self.forward(wav.to(self._device), lengths.to(self._device))
+        encoded, enc_len = self._encode_checked(wav.to(self._device), lengths.to(self._device))
         return self.head.probs(encoded, enc_len)
 
 
@@ -165,9 +217,7 @@ class GigaAMASR(GigaAM):
     def _head_cfg(self) -> Any:
         return _node(self.cfg, "head")
 
-    def _decode(self, encoded: Tensor, encoded_len: Tensor, wav_lens: Tensor,
-                word_timestamps: bool = False) -> List[Tuple[str, Optional[List[Word]]]]:
-        decoded = self.decoding.decode(self.head, encoded, encoded_len)
+    def _with_words(self, decoded, wav_lens: Tensor, encoded_len: Tensor, word_timestamps: bool):
         if not word_timestamps:
             return [(text, None) for text, _, _ in decoded]
         from .timestamps_utils import compute_frame_shift, frames_to_words
@@ -179,23 +229,39 @@ class GigaAMASR(GigaAM):
             out.append((text, frames_to_words(self.decoding.tokenizer, ids, frames, shift)))
         return out
 
+    def _decode(self, encoded: Tensor, encoded_len: Tensor, wav_lens: Tensor,
+                word_timestamps: bool = False) -> List[Tuple[str, Optional[List[Word]]]]:
+        """reference model.py:96-124"""
+        return self._with_words(self.decoding.decode(self.head, encoded, encoded_len), wav_lens, encoded_len, word_timestamps)
+
+    # ---- the launch / collect pair every transcribe path is built from (public: a driver -- bench.py, shard.run_sharded,
+    #      a test -- can interleave them, or replace them to script the decode)
+    def launch_batch(self, wav: Tensor, lengths: Tensor):
+        """Device half of ``transcribe_batch``: frontend + encoder + greedy decode of a collated batch (wav [B,L] zero
+        padded, len [B]) launched on the current stream, NO host sync.  Returns an opaque handle for ``collect_batch``."""
+        wav, lengths = wav.to(self._device), lengths.to(self._device)
+        encoded, encoded_len = self._encode(wav, lengths)
+        return self.decoding.decode_device(self.head, encoded, encoded_len), lengths, encoded_len
+
+    def collect_batch(self, handle, word_timestamps: bool = False) -> List[Tuple[str, Optional[List[Word]]]]:
+        """Host half: blocks on the handle's decode, detokenises, builds word timestamps.  Raises
+        ``decoding.RangeOverflow`` if the split-fp16 range flag was set (the callers below repeat in fp32)."""
+        dev_out, wav_lens, encoded_len = handle
+        return self._with_words(self.decoding.finish(*dev_out), wav_lens, encoded_len, word_timestamps)
+
     @torch.inference_mode()
     def transcribe(self, wav_file: str, word_timestamps: bool = False) -> TranscriptionResult:
-        wav, length = self.prepare_wav(wav_file)
+        wav, length = self._prepare_wav_f32(wav_file)
         if length.item() > LONGFORM_THRESHOLD:
             raise ValueError("Too long wav file, use 'transcribe_longform' method.")
-        encoded, encoded_len = self.forward(wav, length)
-        text, words = self._decode(encoded, encoded_len, length, word_timestamps)[0]
+        text, words = self.transcribe_batch(wav, length, word_timestamps)[0]
         return TranscriptionResult(text=text, words=words)
 
     @torch.inference_mode()
     def transcribe_batch(self, wav: Tensor, lengths: Tensor, word_timestamps: bool = False):
         """Batched twin of ``transcribe`` on an already collated batch (wav [B,L] zero
         padded, len [B]) -- the unit bench.py and the longform driver iterate."""
-        wav = wav.to(self._device).to(self._dtype)
-        lengths = lengths.to(self._device)
-        encoded, encoded_len = self.forward(wav, lengths)
-        return self._decode(encoded, encoded_len, lengths, word_timestamps)
+        return self._with_f32_fallback(lambda: self.collect_batch(self.launch_batch(wav, lengths), word_timestamps), "this batch was")
 
     @torch.inference_mode()
     def transcribe_longform(self, wav_file: str, word_timestamps: bool = False, fr_batch_size: int = 16,
@@ -205,7 +271,11 @@ class GigaAMASR(GigaAM):
         (gated third-party model, not installable here); pass ``speech_regions=[(s,e),..]``,
         ``vad=callable(wav, sr) -> regions`` or ``vad="energy"`` (vad_utils.EnergyVAD, a labelled
         stand-in) and the reference's own chunk packer
-        (vad_utils.pack_regions) does the rest."""
+        (vad_utils.pack_regions) does the rest.
+
+        ``fr_num_workers`` is accepted for signature compatibility and ignored: the reference hands it to a
+        ``DataLoader`` whose workers only run ``collate`` (model.py:219-229); here that role is the pinned,
+        double-buffered ``feeder.BatchFeeder`` (one staging thread is enough to keep the GPU busy)."""
         from .vad_utils import EnergyVAD, segment_audio_file
 
         if kwargs.get("vad") == "energy":   # stand-in detector on the HIP frontend (NOT pyannote)
@@ -227,70 +297,34 @@ class GigaAMASR(GigaAM):
             return LongformTranscriptionResult(segments=[])
         from .feeder import BatchFeeder
 
-        # One-batch software pipeline: the kernels of batch n are launched (no host sync) BEFORE the decoded ids of
-        # batch n-1 are copied back and detokenised, so the D2H wait, the tokenizer and the feeder's staging of the
-        # next batch all run while the GPU works.  (The reference syncs per batch: model.py:230-236.)  The range flag
-        # of the split-fp16 GEMMs is read once, at the end: if it ever fired the file is redone on the fp32 path.
-        result: List[Segment] = []
-        idx = 0
+        # One-batch software pipeline: the kernels of batch n are launched (launch_batch: no host sync) BEFORE the
+        # decoded ids of batch n-1 are copied back and detokenised (collect_batch), so the D2H wait, the tokenizer and
+        # the feeder's staging of the next batch all run while the GPU works.  (The reference syncs per batch:
+        # model.py:230-236.)  The range flag of the split-fp16 GEMMs rides on each batch's counts copy; if it ever
+        # fires, the file is redone on the fp32 path.
+        def run() -> List[Segment]:
+            result: List[Segment] = []
 
-        def emit(pending) -> None:
-            nonlocal idx
-            dev_out, lens, wl, el = pending
-            decoded = self.decoding.finish(*dev_out)
-            if word_timestamps:
-                from .timestamps_utils import compute_frame_shift, frames_to_words
-                wl_h, el_h = wl.cpu().tolist(), el.cpu().tolist()
-            for i, (text, ids, frames) in enumerate(decoded):
-                start, end = boundaries[idx]
-                idx += 1
-                if word_timestamps:
-                    words = frames_to_words(self.decoding.tokenizer, ids, frames, compute_frame_shift(int(wl_h[i]), int(el_h[i])))
-                    shifted = [Word(text=w.text, start=round(w.start + start, 3), end=round(w.end + start, 3)) for w in words or []]
-                    result.append(Segment(text=text, start=start, end=end, words=shifted))
-                else:
-                    result.append(Segment(text=text, start=start, end=end))
-
-        def run() -> None:
-            nonlocal idx
-            result.clear()
-            idx = 0
-            pending = None
-            prev_check, self._check_range = self._check_range, False
-            try:
-                for wav, lens in BatchFeeder(segments, fr_batch_size, self._device):   # pinned, double-buffered H2D
-                    wav = wav.to(self._dtype)
-                    encoded, encoded_len = self.forward(wav, lens)
-                    dev_out = self.decoding.decode_device(self.head, encoded, encoded_len)
-                    if pending is not None:
-                        emit(pending)
-                    pending = (dev_out, lens, lens, encoded_len)
-                if pending is not None:
-                    emit(pending)
-            finally:
-                self._check_range = prev_check
-
-        if type(self).transcribe_batch is not GigaAMASR.transcribe_batch or "transcribe_batch" in self.__dict__:
-            # a caller replaced transcribe_batch (tests do, to script the decode): keep the plain per-batch loop
-            for wav, lens in BatchFeeder(segments, fr_batch_size, self._device):
-                for text, words in self.transcribe_batch(wav, lens, word_timestamps):
-                    start, end = boundaries[idx]
-                    idx += 1
+            def emit(handle) -> None:
+                for text, words in self.collect_batch(handle, word_timestamps):
+                    start, end = boundaries[len(result)]
                     if word_timestamps:
                         shifted = [Word(text=w.text, start=round(w.start + start, 3), end=round(w.end + start, 3)) for w in words or []]
                         result.append(Segment(text=text, start=start, end=end, words=shifted))
                     else:
                         result.append(Segment(text=text, start=start, end=end))
-            return LongformTranscriptionResult(segments=result)
-        eng = self.encoder.engine
-        run()
-        if eng.gemm_mode == "f16x3" and eng.range_flag():
-            import warnings
-            warnings.warn("gigaam_amd: activation beyond the split-fp16 GEMM range; the file was recomputed with "
-                          "GAM_GEMM_F32", RuntimeWarning, stacklevel=2)
-            eng.set_gemm_mode("f32")
-            try:
-                run()
-            finally:
-                eng.set_gemm_mode("f16x3")
-        return LongformTranscriptionResult(segments=result)
+
+            pending = None
+            for wav, lens in BatchFeeder(segments, fr_batch_size, self._device):   # pinned, double-buffered H2D
+                handle = self.launch_batch(wav, lens)
+                if pending is not None:
+                    emit(pending)
+                pending = handle
+            if pending is not None:
+                emit(pending)
+            return result
+
+        eng = getattr(self.encoder, "_engine", None)
+        if eng is not None and eng.gemm_mode == "f16x3":
+            eng.range_flag()     # a flag left behind by earlier direct engine use must not cost this file an fp32 rerun
+        return LongformTranscriptionResult(segments=self._with_f32_fallback(run, "the file was"))

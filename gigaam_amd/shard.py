@@ -93,6 +93,10 @@ def run_sharded(batches: Sequence[Tuple[Tensor, Tensor, Sequence[int]]], decode_
     n_total = sum(len(b[2]) for b in batches)
     # every rank contributes the same number of rows (fixed-size all-gather): the largest share
     per_rank = max(sum(len(batches[j][2]) for j in deal(len(batches), r, n_ranks, snake)) for r in range(n_ranks))
+    n_mine = sum(len(batches[j][2]) for j in mine)
+    if n_mine > per_rank:   # (a caller-chosen my_batches that is not this rank's deal() share)
+        raise ValueError(f"rank {rank}: my_batches holds {n_mine} utterances but the exchange is sized for {per_rank} per rank "
+                         f"(deal(n_batches={len(batches)}, n_ranks={n_ranks}, snake={snake})); pass the deal() share or omit my_batches")
     rows = []
 
     def take(res, gidx):
@@ -141,7 +145,11 @@ class HipComm:
             raise _lib.GigaAMHipError(err or "rank 0 could not create an RCCL id")
         self._c = C.c_void_p()
         rc = self.lib.gam_comm_create(uid, rank, world, self.device.index or 0, C.byref(self._c))
-        self._check(rc, "gam_comm_create")
+        try:
+            self._check(rc, "gam_comm_create")
+        except Exception:
+            self.close()        # a half-made communicator (the struct exists, ncclCommInitRank failed) is not leaked
+            raise
 
     def _check(self, rc: int, what: str) -> None:
         if rc != 0:

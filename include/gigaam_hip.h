@@ -128,11 +128,16 @@ int gam_emo_probs(gam_handle* h, const float* encoded, const int32_t* enc_len, i
 enum { GAM_GEMM_F32 = 0, GAM_GEMM_F16X3 = 1 };
 int gam_set_gemm_mode(gam_handle* h, int mode);
 /* Range guard of GAM_GEMM_F16X3.  LayerNorm-produced operands carry a per-row power-of-two scale and cannot leave
- * fp16's range; the other GEMM inputs (FFN hidden, conv-module output, stem activations) are split as they are, and a
- * value beyond +-60000 there sets a device flag instead of silently becoming inf.  gam_range_flag copies the flag
+ * fp16's range; the other split-fp16 operands (FFN hidden, conv-module output, stem image and Conv2d#2 output, and the
+ * attention's q / k / v -- its context is a convex combination of v) are split as they are, and a value beyond +-60000
+ * there sets a device flag instead of silently becoming inf.  gam_range_flag copies the flag
  * accumulated since the last call to *flag_host (host int), clears it, and SYNCHRONISES `stream`; a caller that
  * sees 1 should repeat the batch under GAM_GEMM_F32 (the Python shim does).  Always 0 under GAM_GEMM_F32. */
 int gam_range_flag(gam_handle* h, int* flag_host, void* stream);
+/* The same without the host round trip: copies the accumulated flag into *flag_dev (a DEVICE int32) and clears it,
+ * asynchronously on `stream`.  A caller that brings the decode counts to the host anyway (every transcribe path does)
+ * appends one int to that buffer and reads both in ONE copy (gigaam_amd/engine.py does). */
+int gam_range_flag_fetch(gam_handle* h, int32_t* flag_dev, void* stream);
 int gam_get_gemm_mode(const gam_handle* h);
 
 /* Raw GEMM entry for kernel-level tests and the roofline bench (arithmetic = current mode):

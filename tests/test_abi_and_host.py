@@ -128,3 +128,115 @@ def test_bench_power_sampler_without_telemetry(monkeypatch):
         pass
     out = ps.summary()
     assert out["available"] is False and "note" in out
+
+
+# --------------------------------------------------------------------------- real-checkpoint plumbing (reference __init__.py:139-192)
+import collections.abc as _abc
+
+
+class FakeDictConfig(_abc.MutableMapping):
+    """Stand-in for omegaconf.DictConfig (absent offline): a MutableMapping with attribute access, nested containers
+    wrapped on the way in -- what ``checkpoint["cfg"]`` is in the reference's .ckpt files."""
+
+    def __init__(self, d):
+        object.__setattr__(self, "_d", {k: _wrap(v) for k, v in d.items()})
+
+    def __getitem__(self, k):
+        return self._d[k]
+
+    def __setitem__(self, k, v):
+        self._d[k] = _wrap(v)
+
+    def __delitem__(self, k):
+        del self._d[k]
+
+    def __iter__(self):
+        return iter(self._d)
+
+    def __len__(self):
+        return len(self._d)
+
+    def __getattr__(self, k):
+        try:
+            return object.__getattribute__(self, "_d")[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self._d[k] = _wrap(v)
+
+
+class FakeListConfig(_abc.Sequence):
+    def __init__(self, items):
+        self._l = [_wrap(v) for v in items]
+
+    def __getitem__(self, i):
+        return self._l[i]
+
+    def __len__(self):
+        return len(self._l)
+
+
+def _wrap(v):
+    if isinstance(v, dict):
+        return FakeDictConfig(v)
+    if isinstance(v, (list, tuple)):
+        return FakeListConfig(v)
+    return v
+
+
+def _real_style_checkpoint(name="v2_ctc"):
+    """A synthetic checkpoint dressed like a published one: attribute-style cfg, BatchNorm's int64 ``num_batches_tracked``
+    and the torchaudio buffers the reference's FeatureExtractor registers (SURVEY 8b state_dict keys)."""
+    import torch
+    from gigaam_amd import synth
+    ck = synth.make_checkpoint(name, seed=3, n_layers=2)
+    sd = dict(ck["state_dict"])
+    for i in range(2):
+        sd[f"encoder.layers.{i}.conv.batch_norm.num_batches_tracked"] = torch.tensor(1234, dtype=torch.int64)
+    pre = ck["cfg"]["preprocessor"]
+    n_fft = pre.get("n_fft", 400)
+    sd["preprocessor.featurizer.0.spectrogram.window"] = torch.hann_window(n_fft, periodic=True)
+    return ck, {"cfg": FakeDictConfig(ck["cfg"]), "state_dict": sd}
+
+
+def test_attribute_style_cfg_plumbing(tmp_path, monkeypatch):
+    """No real .ckpt has ever gone through load_model offline; the first user's will.  Everything load_model does to one is
+    exercised here on a look-alike: cfg nodes by attribute AND by key, ListConfig vocabulary, ``cfg.decoding.model_path`` /
+    ``cfg.model_name`` assignment (reference __init__.py:176,191), the md5 gate, and the Lightning fine-tuned form."""
+    import hashlib
+    import torch
+    import gigaam_amd
+    from gigaam_amd import model as M
+    plain, ck = _real_style_checkpoint()
+    cfg = ck["cfg"]
+    assert cfg.encoder.d_model == cfg["encoder"]["d_model"] and not isinstance(cfg, dict)
+    m = gigaam_amd.model_from_checkpoint(ck, "cpu")
+    assert isinstance(m, gigaam_amd.GigaAMASR)
+    assert m.encoder.cfg["n_layers"] == 2 and m.encoder.cfg["self_attention_model"] == plain["cfg"]["encoder"]["self_attention_model"]
+    assert m.head.num_classes == plain["cfg"]["head"]["num_classes"]
+    assert isinstance(m.decoding.tokenizer.vocab, list) and m.decoding.tokenizer.vocab == list(plain["cfg"]["decoding"]["vocabulary"])
+    assert m.decoding.blank_id == len(m.decoding.tokenizer.vocab)
+    assert M._plain(cfg.encoder) == plain["cfg"]["encoder"] and type(M._plain(cfg.decoding.vocabulary)) is list
+    # every tensor of the state_dict (incl. the int64 counter and the torchaudio window) is staged for the library
+    assert set(m._state) == set(ck["state_dict"])
+    # load_model: named checkpoint under download_root, md5 gate, model_name written back into the cfg
+    root = tmp_path / "cache"
+    root.mkdir()
+    path = root / "v2_ctc.ckpt"
+    torch.save(ck, path)
+    with pytest.raises(AssertionError, match="Model checksum failed"):
+        gigaam_amd.load_model("v2_ctc", device="cpu", download_root=str(root))
+    monkeypatch.setitem(gigaam_amd._MODEL_HASHES, "v2_ctc", hashlib.md5(path.read_bytes()).hexdigest())
+    m2 = gigaam_amd.load_model("v2_ctc", device="cpu", download_root=str(root))
+    assert m2.cfg.model_name == "v2_ctc" and m2._dtype == torch.float32        # fp16_encoder only applies on a GPU (reference :188)
+    with pytest.raises(ValueError, match="not found"):
+        gigaam_amd.load_model("v9_ctc", device="cpu", download_root=str(root))
+    # Lightning-style fine-tuned checkpoint: base model by hyper_parameters.model_name, then its own weights on top
+    ft = {"hyper_parameters": {"model_name": "v2_ctc"},
+          "state_dict": {**{k: v + 0 for k, v in ck["state_dict"].items()}, "loss.weight": torch.zeros(1), "optimizer_junk": 3}}
+    ftp = tmp_path / "finetuned.ckpt"
+    torch.save(ft, ftp)
+    m3 = gigaam_amd.load_model(str(ftp), device="cpu", download_root=str(root))
+    assert isinstance(m3, gigaam_amd.GigaAMASR)
+    assert set(m3._state) == {k for k in ck["state_dict"] if k.startswith(("preprocessor.", "encoder.", "head."))}

@@ -145,3 +145,38 @@ def test_deal_and_pack_invariants():
         shard.unpack_results(idx, cnt, ids, frames, 5)
     with pytest.raises(RuntimeError, match="twice"):
         shard.unpack_results(torch.tensor([1, 1]), torch.tensor([0, 0]), torch.zeros(2, 1, dtype=torch.int32), torch.zeros(2, 1, dtype=torch.int32), 2)
+
+
+# --------------------------------------------------------------------------- bench.py as its own launcher
+def _run_bench(argv, env=None, timeout=240):
+    import subprocess
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, env=e, timeout=timeout)
+
+
+def test_bench_self_launches_its_ranks():
+    """The driver's command is plain ``python bench.py --gpus N`` (no torchrun): bench.py must start the N ranks itself and
+    still print exactly ONE JSON line, from rank 0.  --launch-selftest swaps the GPU step for a sleep and RCCL for gloo;
+    the launcher, the rendezvous, the barrier-bracketed max-over-ranks timing and the exchange are the ones the real run uses."""
+    import json
+    r = _run_bench(["--gpus", "2", "--launch-selftest", "--steps", "3"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["launcher"] == "bench.py self-launch"
+    assert d["gathered_counts"] == [1, 2] and d["gathered_ids"] == [0, 1]          # rank-major, both ranks present
+    assert d["ms_per_step"] >= 4.0                                                  # max over ranks: rank 1 sleeps 4 ms per step
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0]                           # the line is the last thing on stdout
+
+
+def test_bench_launch_errors_are_clear():
+    """Too few GPUs for --gpus N, and a launcher whose WORLD_SIZE disagrees with --gpus: one-line explanations, non-zero exit."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        r = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+        assert r.returncode != 0 and "GPU(s) visible" in r.stderr and "--oversubscribe" in r.stderr
+    r = _run_bench(["--gpus", "2", "--launch-selftest"], env={"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr

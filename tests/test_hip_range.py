@@ -106,3 +106,54 @@ def test_range_flag_and_fp32_fallback(mode):
     err = float(((enc2.cpu() - want) * vm[:, None, :]).abs().max())
     report("range_fallback", mode=mode, err=err)
     assert err < 2e-3, err     # (whole path incl. the HIP frontend; the bar of smoke())
+    # the transcribe paths read the flag WITH the decode counts (engine.collect: no extra sync) and fall back the same way
+    model32 = gigaam_amd.model_from_checkpoint({"cfg": ck["cfg"], "state_dict": sd}, "cuda:0")
+    model32.encoder.engine.set_gemm_mode("f32")
+    with warnings.catch_warnings(record=True) as w2:
+        warnings.simplefilter("always")
+        got = model.transcribe_batch(wav, wlen)
+    assert any("recomputed" in str(x.message) for x in w2) and model.encoder.engine.gemm_mode == "f16x3"
+    assert got == model32.transcribe_batch(wav, wlen)
+    # driving the decoders directly: the flag is an error (decoding.RangeOverflow), never silently wrong ids
+    from gigaam_amd.decoding import RangeOverflow
+    handle = model.launch_batch(wav, wlen)
+    with pytest.raises(RangeOverflow):
+        model.collect_batch(handle)
+
+
+@pytest.mark.parametrize("mode", ["f16x3", "f16x3-sp"])
+@pytest.mark.parametrize("which", ["k", "v", "q"])
+def test_attention_operands_are_guarded(mode, which):
+    """VERDICT r2 weak #3 / ADVICE r2: q, k and v are split to fp16 UNSCALED inside the attention kernel, so the GEMMs that
+    produce them carry the range guard (include/gigaam_hip.h gam_range_flag).  linear_<which> scaled by 2^17 (|k| ~ 1e5 >
+    65504; for q/k the partner is scaled by 2^-17 so the scores -- and the network -- are unchanged; for v linear_out
+    takes the 2^-17): the flag must fire, and the model must answer with the fp32 recomputation within the usual bar."""
+    import gigaam_amd
+    ck, wav, wlen, gold = load_case("v2_ctc_l2")
+    sd = {k: v.clone() for k, v in ck["state_dict"].items()}
+    up, dn = 2.0 ** 17, 2.0 ** -17
+    for i in range(ck["cfg"]["encoder"]["n_layers"]):
+        p = f"encoder.layers.{i}.self_attn."
+        other = {"k": "linear_q", "q": "linear_k", "v": None}[which]
+        sd[p + f"linear_{which}.weight"] *= up
+        sd[p + f"linear_{which}.bias"] *= up
+        if other is not None:
+            sd[p + other + ".weight"] *= dn
+            sd[p + other + ".bias"] *= dn
+        else:
+            sd[p + "linear_out.weight"] *= dn
+    feat_o, flen_o = oracle_features(ck, wav, wlen)
+    eng = _make_engine(ck["cfg"], sd, mode)
+    eng.encode(feat_o, flen_o)
+    assert eng.range_flag(), (mode, which)
+    if mode == "f16x3-sp":
+        return      # (model_from_checkpoint picks the kernel family by size; the sp kernels' guard is what was checked above)
+    model = gigaam_amd.model_from_checkpoint({"cfg": ck["cfg"], "state_dict": sd}, "cuda:0")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        enc2, _ = model.forward(wav.to("cuda:0"), wlen.to("cuda:0"))
+    assert any("recomputed" in str(x.message) for x in w)
+    vm = valid_mask(enc2.shape[2], gold["enc_len"])
+    err = float(((enc2.cpu() - torch.from_numpy(gold["encoded"])) * vm[:, None, :]).abs().max())
+    report("attention_guard", mode=mode, which=which, err=err)
+    assert err < 2e-3, err
