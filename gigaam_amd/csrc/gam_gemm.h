@@ -74,6 +74,7 @@ struct GamGemmArgs {
   // value beyond fp16's range written to C sets *range_flag (gam_common.h gam_range_note); may be null.
   int* range_flag;
   int c_guard;
+  long long* tlog;      // instrumented builds (GAM_SP_INSTRUMENT, GAM_SP_DBG & 16): per-workgroup timeline, 8 words per tile
   int prio;             // LDS-DMA GEMM: s_setprio 1 for the later-dispatched half of the waves (GAM_SP_PRIO, A/B switch)
 };
 

@@ -26,6 +26,10 @@
 // last round of tiles.
 #pragma once
 #include "gam_gemm16.h"
+#if defined(GAM_SP_INSTRUMENT) && GAM_SP_INSTRUMENT
+#include <algorithm>
+#include <vector>
+#endif
 
 // -DGAM_SP_INSTRUMENT=1 compiles the GAM_SP_DBG experiment switches in (1: skip the epilogue, 2: one
 // k-tile only, 4: per-phase clock64 counters written into the last C row, 8: drop the in-loop barrier).
@@ -34,6 +38,19 @@
 #define GAM_SP_INSTRUMENT 0
 #endif
 #define GAM_SP_DBG(g) (GAM_SP_INSTRUMENT ? (g).dbg : 0)
+// GAM_SP_DBG & 16 (instrumented builds): per-workgroup timeline -- wall clock (100 MHz) at entry / operands of the first two
+// k-tiles landed / main loop done / epilogue done, shader clock around the loop -- into g.tlog[tile * 8 ..]; the launcher
+// prints the distribution (tools/gemm_sp_test.py; profiles/r03_gemm_timeline.txt).
+#if GAM_SP_INSTRUMENT
+#define GAM_SP_TL(i)                                                                  \
+  if ((g.dbg & 16) && g.tlog != nullptr && threadIdx.x == 0) {                        \
+    g.tlog[(size_t)lid * 8 + (i)] = wall_clock64();                                   \
+    if ((i) == 1 || (i) == 2) g.tlog[(size_t)lid * 8 + 4 + (i)] = clock64();          \
+    if ((i) == 0) g.tlog[(size_t)lid * 8 + 7] = blockIdx.x;                            \
+  }
+#else
+#define GAM_SP_TL(i)
+#endif
 
 #define GAM_SP_MIN_M 2048   // below this the 128x128 kernels fill the chip better
 
@@ -72,6 +89,7 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
   const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   const int m0 = (lid / nbn) * BM;
   const int n0 = (lid % nbn) * BN;
+  GAM_SP_TL(0);
 
   // ---- DMA sources.  Piece q of an operand = tile rows 8q .. 8q+7; this wave moves pieces
   //      q = wave + NWAVES i.  Lane l -> row 8q + (l>>3), LDS slot' l&7, source slot (l&7) ^ ((row>>1)&7).
@@ -176,8 +194,8 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
 #define GAM_SP_MFMA(S, T)                                                                         \
   {                                                                                               \
     const int term_ = (T) / (2 * MT), i_ = ((T) % (2 * MT)) / 2, j_ = (T) & 1;                    \
-    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term_ == 2 ? fal[S][i_] : fah[S][i_],    \
-                                                         term_ == 1 ? fbl[S][j_] : fbh[S][j_], acc[i_][j_], 0, 0, 0); \
+    acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term_ == 1 ? fbl[S][j_] : fbh[S][j_],    \
+                                                         term_ == 2 ? fal[S][i_] : fah[S][i_], acc[i_][j_], 0, 0, 0); \
   }
   // phase<S, DMA>: MFMAs of set S; reads of set 1-S from (rst, roh, rol); DMA pieces of the next tile -> stage istage
   auto phase = [&](auto setc, auto dmac, const unsigned char* rst, int roh, int rol, int istage) {
@@ -223,6 +241,7 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
   issue(1);   // (nk == 1: fetches tile 0 again, unused)
   __builtin_amdgcn_s_waitcnt(0x0070);
   __syncthreads();   // both tiles have landed for every wave
+  GAM_SP_TL(1);
 #pragma unroll
   for (int q = 0; q < NR; ++q) GAM_SP_RDITEM(0, q, gam_smem_sp, o_h0, o_l0);
   const int nk_run = (GAM_SP_DBG(g) & 2) ? 1 : nk;
@@ -255,77 +274,88 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
 #undef GAM_SPLD
 #undef GAM_SP_RDITEM
 #undef GAM_SP_MFMA
-  // the last phases' stale set-0 reads and surplus DMA pieces must not race the scratch writes below
+  // every LDS-DMA piece of this wave has landed (a workgroup must not retire with DMA writes in flight: its LDS
+  // could already belong to the next one); no barrier -- the epilogue below touches no shared memory
   __builtin_amdgcn_s_waitcnt(0x0070);
-  __syncthreads();
+  GAM_SP_TL(2);
 
   const int mw = m0 + wm * (BM / 2), nw = n0 + wn * 64;
   if ((GAM_SP_DBG(g) & 1) && acc[0][0][0] != 123.456f) return;
 
-  // ---- epilogue.  Each wave transposes its 32 x 64 slabs through a private LDS scratch (the stages
-  //      are dead: the last reads completed before the final barrier, no DMA is outstanding) so that
-  //      a lane owns 4 consecutive columns of a row: bias / residual / C move as 16-byte vectors,
-  //      4 rows x 256 B per instruction, and the per-row index math runs once per row.
-  constexpr int TLD = 68;   // floats per scratch row (272 B: rows of a read group fall on distinct banks)
-  float* T = reinterpret_cast<float*>(gam_smem_sp) + wave * (32 * TLD);
-  const int ecol = nw + (lane & 15) * 4;
-  const bool colok = ecol < g.N;   // N % 4 == 0 (launcher)
-  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-  if (g.bias != nullptr && colok) bv = *reinterpret_cast<const f32x4*>(g.bias + ecol);
+  // ---- epilogue, straight from the accumulators.  The MFMAs run with the operands SWAPPED (W fragment as the A
+  //      operand, activation fragment as B), i.e. they accumulate C^T tiles: lane l then owns ONE row of C
+  //      (m = l & 31 of the 32 x 32 tile) and, per register quad g = r >> 2, FOUR CONSECUTIVE columns
+  //      n = 8 g + 4 (l >> 5) + (r & 3).  Bias / residual / C therefore move as 16-byte vectors with no transpose:
+  //      the former per-wave LDS round trip (96 ds_write_b32 + 24 ds_read_b128 per wave, 8 waves on one LDS) cost
+  //      5.0 of the 7.3 us a 192 x 256 tile spent here (profiles/r03_gemm_timeline.txt); lanes l and l + 32 write
+  //      adjacent 16-byte pieces of a row, the four quads complete its 128-byte line.
+  const int lrow = lane & 31, lq = (lane >> 5) * 4;
   const float accscale = g.wscale_inv;
-  // per-row factor of this lane's rows (weight scale x the A operand's row scale), all loads in flight together
-  // (a load inside the row loop below sits behind its branches: one L2 round trip per row, +10 us per launch)
-  float rsv[MT][8];
+  f32x4 bv[2][4];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      int row = mw + 32 * i + it * 4 + (lane >> 4);
-      row = row < g.M ? row : g.M - 1;
-      rsv[i][it] = g.a_rs != nullptr ? g.a_rs[row] : 1.0f;
+    for (int q = 0; q < 4; ++q) {
+      const int col = nw + 32 * j + 8 * q + lq;
+      bv[j][q] = (g.bias != nullptr && col < g.N) ? *reinterpret_cast<const f32x4*>(g.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};   // N % 4 == 0
     }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
+    const int row = mw + 32 * i + lrow;
+    if (row >= g.M) continue;
+    bool masked = false, skip = false;
+    long orow = row;
+    if (g.lens != nullptr || g.remap) {
+      const int bb = row / g.rpb, tt = row - bb * g.rpb;
+      if (g.lens != nullptr) masked = (tt / g.fdiv) >= g.lens[bb];
+      if (g.remap) {
+        skip = tt >= g.rows_valid;
+        orow = (long)bb * g.out_rpb + tt + g.out_shift;
+      }
+    }
+    if (skip) continue;
+    // per-row factor (weight scale x the A operand's row scale)
+    const float rsc = accscale * (g.a_rs != nullptr ? g.a_rs[row] : 1.0f);
+    f32x4 rv[2][4];
+    if (g.R != nullptr) {   // all eight residual pieces of the row in flight before the first use
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = nw + 32 * j + 8 * q + lq;
+          rv[j][q] = col < g.N ? *reinterpret_cast<const f32x4*>(g.R + orow * g.ldr + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        T[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * TLD + 32 * j + (lane & 31)] = acc[i][j][r];
-    // (same wave wrote and reads: only the LDS counter orders them, no barrier)
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int lr = it * 4 + (lane >> 4);
-      const int row = mw + 32 * i + lr;
-      f32x4 v = *reinterpret_cast<const f32x4*>(T + lr * TLD + (lane & 15) * 4);
-      if (row >= g.M || !colok) continue;
-      bool masked = false;
-      long orow = row;
-      if (g.lens != nullptr || g.remap) {
-        const int bb = row / g.rpb, tt = row - bb * g.rpb;
-        if (g.lens != nullptr) masked = (tt / g.fdiv) >= g.lens[bb];
-        if (g.remap) {
-          if (tt >= g.rows_valid) continue;
-          orow = (long)bb * g.out_rpb + tt + g.out_shift;
+      for (int q = 0; q < 4; ++q) {
+        const int ecol = nw + 32 * j + 8 * q + lq;
+        if (ecol >= g.N) continue;
+        f32x4 v = (f32x4){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        v = v * rsc + bv[j][q];
+        if (ACT == GAM_ACT_SILU) { v.x = gam_silu(v.x); v.y = gam_silu(v.y); v.z = gam_silu(v.z); v.w = gam_silu(v.w); }
+        if (ACT == GAM_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (masked) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        v = v * g.alpha;
+        if (g.R != nullptr) v += rv[j][q];
+        if (g.c_guard) gam_range_note(g.range_flag, v.x, v.y, v.z, v.w);
+        if ((GAM_SP_DBG(g) & 32) && v.x != 123.456f) continue;   // (experiment: the whole epilogue except its global stores)
+        if (g.c_split) {
+          _Float16* cp = reinterpret_cast<_Float16*>(g.C) + orow * (2 * g.ldc) + (ecol >> 5) * 64 + (ecol & 31);
+          gam_half4 hi, lo;
+          gam_split4(v, hi, lo);
+          *reinterpret_cast<gam_half4*>(cp) = hi;
+          *reinterpret_cast<gam_half4*>(cp + 32) = lo;
+        } else {
+          *reinterpret_cast<f32x4*>(g.C + orow * g.ldc + ecol) = v;
         }
       }
-      v = v * (accscale * rsv[i][it]) + bv;
-      if (ACT == GAM_ACT_SILU) { v.x = gam_silu(v.x); v.y = gam_silu(v.y); v.z = gam_silu(v.z); v.w = gam_silu(v.w); }
-      if (ACT == GAM_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (masked) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-      v = v * g.alpha;
-      if (g.R != nullptr) v += *reinterpret_cast<const f32x4*>(g.R + orow * g.ldr + ecol);
-      if (g.c_guard) gam_range_note(g.range_flag, v.x, v.y, v.z, v.w);
-      if (g.c_split) {
-        _Float16* cp = reinterpret_cast<_Float16*>(g.C) + orow * (2 * g.ldc) + (ecol >> 5) * 64 + (ecol & 31);
-        gam_half4 hi, lo;
-        gam_split4(v, hi, lo);
-        *reinterpret_cast<gam_half4*>(cp) = hi;
-        *reinterpret_cast<gam_half4*>(cp + 32) = lo;
-      } else {
-        *reinterpret_cast<f32x4*>(g.C + orow * g.ldc + ecol) = v;
-      }
-    }
   }
+#if GAM_SP_INSTRUMENT
+  if (g.dbg & 16) { __builtin_amdgcn_s_waitcnt(0x0070); __syncthreads(); }   // stores issued AND acknowledged by every wave
+  GAM_SP_TL(3);
+#endif
 }
 
 // the vectorised epilogue moves 16-byte pieces of bias / R / C rows
@@ -384,6 +414,15 @@ static inline hipError_t gam_launch_gemm_sp(const GamGemmArgs& a_in, int act, hi
   if (prio < 0) { const char* e = getenv("GAM_SP_PRIO"); prio = e ? atoi(e) : 0; }
   a.dbg = dbg;
   a.prio = prio;
+#if GAM_SP_INSTRUMENT
+  static long long* tl_dev = nullptr;
+  static int tl_cap = 0;
+  if (dbg & 16) {
+    if (grid > tl_cap) { if (tl_dev) (void)hipFree(tl_dev); (void)hipMalloc(&tl_dev, (size_t)grid * 64); tl_cap = grid; }
+    (void)hipMemsetAsync(tl_dev, 0, (size_t)grid * 64, stream);
+    a.tlog = tl_dev;
+  }
+#endif
 #define GAM_LSP(ACTV)                                                            \
   if (nw == 2) switch (mt) {                                                     \
     case 2: gam_launch_gemm_sp_t<ACTV, 2, 2>(a, grid, stream); break;            \
@@ -399,6 +438,34 @@ static inline hipError_t gam_launch_gemm_sp(const GamGemmArgs& a_in, int act, hi
     default: GAM_LSP(GAM_ACT_NONE); break;
   }
 #undef GAM_LSP
+#if GAM_SP_INSTRUMENT
+  if ((dbg & 16) && getenv("GAM_SP_TLOG")) {
+    std::vector<long long> t((size_t)grid * 8);
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpy(t.data(), tl_dev, t.size() * 8, hipMemcpyDeviceToHost);
+    long long t_first = t[0], t_last = 0;
+    for (int i = 0; i < grid; ++i) { t_first = std::min(t_first, t[i * 8]); t_last = std::max(t_last, t[i * 8 + 3]); }
+    auto stat = [&](auto f, const char* name) {
+      std::vector<double> v(grid);
+      for (int i = 0; i < grid; ++i) v[i] = f(i);
+      std::sort(v.begin(), v.end());
+      fprintf(stderr, "    %-26s min %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f us\n", name, v[0], v[grid / 2], v[(size_t)(grid * 0.9)], v[grid - 1]);
+    };
+    fprintf(stderr, "[tlog] M=%d N=%d K=%d MT=%d NW=%d tiles=%d: first entry -> last exit %.2f us\n", a.M, a.N, a.K, mt, nw, grid, (t_last - t_first) * 0.01);
+    stat([&](int i) { return (t[i * 8] - t_first) * 0.01; }, "entry after first entry");
+    stat([&](int i) { return (t[i * 8 + 1] - t[i * 8]) * 0.01; }, "prologue (2 k-tiles land)");
+    stat([&](int i) { return (t[i * 8 + 2] - t[i * 8 + 1]) * 0.01; }, "main loop");
+    stat([&](int i) { return (t[i * 8 + 2] - t[i * 8 + 1]) * 0.01 / (a.K / 32); }, "  per k-tile");
+    stat([&](int i) { return (double)(t[i * 8 + 6] - t[i * 8 + 5]) / std::max<long long>(1, t[i * 8 + 2] - t[i * 8 + 1]) * 100.0; }, "  shader MHz in loop");
+    stat([&](int i) { return (t[i * 8 + 3] - t[i * 8 + 2]) * 0.01; }, "epilogue");
+    stat([&](int i) { return (t_last - t[i * 8 + 3]) * 0.01; }, "idle after exit");
+    double x_loop[8] = {0}; int x_n[8] = {0};
+    for (int i = 0; i < grid; ++i) { const int x = (int)(t[i * 8 + 7] & 7); x_loop[x] += (t[i * 8 + 2] - t[i * 8 + 1]) * 0.01; ++x_n[x]; }
+    fprintf(stderr, "    mean loop us by XCD:");
+    for (int x = 0; x < 8; ++x) fprintf(stderr, " %.1f", x_n[x] ? x_loop[x] / x_n[x] : 0.0);
+    fprintf(stderr, "\n");
+  }
+#endif
   return hipGetLastError();
 }
 

@@ -1,0 +1,122 @@
+"""Full-size golden for BASELINE.json config 5 (v2_ctc longform) -- runs ONLY in the build container.
+
+Config 5 cuts one hour of audio into chunks of up to 30 s (reference gigaam/vad_utils.py:80-136), i.e. up to T' = 751
+encoder frames -- a length no other configuration reaches (configs 2-4 stop at 501).  This script runs the REFERENCE's
+own 16-layer ConformerEncoder / CTCHead / CTCGreedyDecoding (through oracle/ref_shim.py) on THREE chunks: a 30 s window
+of the same audio (the packer's strict limit, T' = 751 -- config 5's own chunks stop at 22 s because its synthetic speech
+regions are short), the longest chunk of the very chunk list bench.py --config 5 times, and the one of a small pool of other
+long chunks whose CTC argmax margin is widest (near-ties of a random-init head are below any fp32 implementation's
+reproducibility; the margins of the kept chunks are recorded).  The three are decoded as ONE zero-padded batch, as
+transcribe_longform would (reference gigaam/model.py:219-236, AudioDataset.collate), so the key-padding masks of the
+shorter ones are exercised too.  ``cpu_leg_chunks`` lists the chunks (margin >= 1e-3) bench.py's CPU-oracle leg decodes.
+
+    python tests/golden/make_longform_golden.py      ->  fullsize_v2_ctc_longform.npz, fullsize_meta.json
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+from gigaam_amd import synth, workloads  # noqa: E402
+from gigaam_amd.feeder import collate  # noqa: E402
+from oracle import gigaam_oracle as O  # noqa: E402
+from oracle.ref_shim import import_reference  # noqa: E402
+from make_golden import kw, strip  # noqa: E402
+
+NAME = "fullsize_v2_ctc_longform"
+N_POOL = 4       # other long chunks examined next to the longest
+STRICT_S = 30.0  # the packer's strict_limit_duration (vad_utils.py:84): the longest chunk transcribe_longform can ever see
+STRICT_OFFSETS = [100.0, 1000.0, 2000.0]   # candidate 30 s windows of the same hour of audio (none of config 5's own chunks
+                                           # is that long: its synthetic speech regions pack to <= 22 s)
+
+
+def main():
+    torch.set_num_threads(min(32, os.cpu_count()))
+    ref = import_reference()
+    segs, bounds = workloads.config5_segments(3600)
+    order = sorted(range(len(segs)), key=lambda i: -int(segs[i].shape[0]))
+    longest, pool = order[0], order[1:1 + N_POOL]
+    ck = synth.make_checkpoint("v2_ctc", seed=0)
+    cfg, sd = ck["cfg"], ck["state_dict"]
+    enc = ref.encoder.ConformerEncoder(**kw(cfg["encoder"])).eval()
+    enc.load_state_dict(strip(sd, "encoder."))
+    head = ref.decoder.CTCHead(**kw(cfg["head"])).eval()
+    head.load_state_dict(strip(sd, "head."))
+    dec = ref.decoding.CTCGreedyDecoding(cfg["decoding"]["vocabulary"])
+
+    def run(idx):
+        wav, wlen = collate([segs[i] for i in idx])
+        with torch.no_grad():
+            feat, flen = O.log_mel(wav, wlen, cfg["preprocessor"], sd["preprocessor.featurizer.0.spectrogram.window"],
+                                   sd["preprocessor.featurizer.0.mel_scale.fb"])
+            y, l = enc(feat, flen)
+            lp = head(y)
+        valid = torch.arange(y.shape[2])[None, :] < l[:, None]
+        top2 = lp.topk(2, dim=-1).values
+        marg = torch.where(valid, top2[..., 0] - top2[..., 1], torch.full_like(top2[..., 0], 1e9)).min(dim=1).values
+        return wav, wlen, feat, flen, y, l, marg
+
+    # margins of the candidates, each paired with the longest chunk
+    best, pair_margins = None, {}
+    for c in pool:
+        *_, marg = run([longest, c])
+        print(f"pair ({longest}, {c}): frames {int(segs[longest].shape[0])}, {int(segs[c].shape[0])}; min margins {[round(float(m), 6) for m in marg]}", flush=True)
+        pair_margins[longest] = float(marg[0])
+        pair_margins[c] = float(marg[1])
+        score = float(marg.min())
+        if best is None or score > best[0]:
+            best = (score, c)
+    # the strict-limit case: a 30 s window (T' = 751), the widest-margin one of a few offsets
+    audio = workloads.config5_audio(3600)
+    n30 = int(STRICT_S * 16000)
+    sbest = None
+    for off in STRICT_OFFSETS:
+        w30 = audio[int(off * 16000): int(off * 16000) + n30]
+        segs.append(w30)
+        *_, marg = run([len(segs) - 1])
+        segs.pop()
+        print(f"30 s window at {off} s: min margin {float(marg[0]):.6f}", flush=True)
+        if sbest is None or float(marg[0]) > sbest[0]:
+            sbest = (float(marg[0]), off)
+    segs.append(audio[int(sbest[1] * 16000): int(sbest[1] * 16000) + n30])      # index len(segs)-1 = the synthetic 30 s chunk
+    idx = [len(segs) - 1, longest, best[1]]
+    wav, wlen, feat, flen, y_ref, l_ref, marg = run(idx)
+    with torch.no_grad():
+        y_or, l_or = O.encoder_forward(sd, cfg["encoder"], feat, flen)
+        valid = (torch.arange(y_ref.shape[2])[None, :] < l_ref[:, None])[:, None, :]
+        d_enc = float(((y_ref - y_or) * valid).abs().max())
+        assert l_ref.tolist() == l_or.tolist() and d_enc < 5e-5, d_enc
+        r = dec.decode(head, y_ref, l_ref)
+        o = O.ctc_greedy(O.ctc_log_probs(sd, y_ref), l_ref)
+    ids_flat, frames_flat, counts = [], [], []
+    for (_t, ids, fr), (oi, of) in zip(r, o):
+        assert ids == oi and fr == of
+        ids_flat += ids
+        frames_flat += fr
+        counts.append(len(ids))
+    out = dict(enc_len=l_ref.numpy(), enc_probe=y_ref[:, ::16, ::5].numpy(), wav_len=wlen.numpy(), utt_index=np.asarray([-1] + idx[1:], np.int32),
+               ids=np.asarray(ids_flat, np.int32), frames=np.asarray(frames_flat, np.int32), counts=np.asarray(counts, np.int32))
+    np.savez_compressed(os.path.join(HERE, NAME + ".npz"), **out)
+    cpu_leg = sorted(pair_margins, key=lambda i: -pair_margins[i])[:4]       # bench.py --config 5's CPU-oracle leg decodes these
+    if longest not in cpu_leg:
+        cpu_leg = [longest] + cpu_leg[:3]
+    st = dict(model="v2_ctc", n_utts=len(idx), chunk_index=[-1] + idx[1:], strict_window_offset_s=sbest[1], strict_window_s=STRICT_S,
+              n_chunks=len(segs) - 1, enc_absdiff_oracle_vs_ref=d_enc, frames=l_ref.tolist(),
+              min_margin=float(marg.min()), margins=[float(m) for m in marg], counts=counts,
+              chunk_seconds=[round(float(s.shape[0]) / 16000.0, 3) for s in (segs[i] for i in idx)],
+              cpu_leg_chunks=cpu_leg, cpu_leg_margins=[pair_margins[i] for i in cpu_leg])
+    meta_path = os.path.join(HERE, "fullsize_meta.json")
+    meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
+    meta[NAME] = st
+    json.dump(meta, open(meta_path, "w"), indent=1, sort_keys=True)
+    print(NAME, json.dumps(st), flush=True)
+
+
+if __name__ == "__main__":
+    main()
