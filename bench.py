@@ -519,6 +519,14 @@ def main():
             from gigaam_amd.feeder import collate
             order = sorted(range(len(segs)), key=lambda i: -int(segs[i].shape[0]))
             pick = [order[0]] + [i for i in (0, len(segs) // 2, len(segs) - 1) if i != order[0]][:3]
+            # Over 194 chunks x ~550 frames a random-init head has frames whose top-2 margin is below any fp32 implementation's
+            # reproducibility; the full-size golden generator (tests/golden/make_longform_golden.py) examined the longest chunks
+            # with the REFERENCE's modules and recorded the ones whose margin exceeds 1e-3 -- those are decoded here.
+            mp = os.path.join(ROOT, "tests", "golden", "fullsize_meta.json")
+            if os.path.exists(mp):
+                m5 = json.load(open(mp)).get("fullsize_v2_ctc_longform", {})
+                if m5.get("n_chunks") == len(segs) and m5.get("cpu_leg_chunks") and order[0] in m5["cpu_leg_chunks"]:
+                    pick = [order[0]] + [i for i in m5["cpu_leg_chunks"] if i != order[0]][:3]
             w5, l5 = collate([segs[i] for i in pick])
             cpu_sample = (w5, l5, pick)
 

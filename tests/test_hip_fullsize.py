@@ -142,3 +142,37 @@ def test_fullsize_rnnt_matches_reference(name):
         worst = max(worst, float((got_v - want_v).abs().max()))
     report("fullsize_rnnt_joint_logprobs", case=name, err=worst, tol=1e-3, steps=sum(tc), symbols_per_frame=meta["symbols_per_frame"])
     assert worst < 1e-3, worst
+
+
+def test_fullsize_config5_longform_chunks_match_reference():
+    """BASELINE config 5 at full size: the REFERENCE's 16-layer modules on three chunks decoded as one
+    zero-padded batch, as transcribe_longform would -- a 30 s window of the hour (the packer's strict limit: T' = 751, the
+    longest chunk the path can ever see), the longest chunk of the list bench.py --config 5 times and a second long one
+    (tests/golden/make_longform_golden.py; margins > 1e-3 by selection).  Encoder probe <= 2e-4, ids + frames bit-exact."""
+    import json
+    import os
+
+    import numpy as np
+    from common import ROOT, report
+    from gigaam_amd import synth, workloads
+    from gigaam_amd.engine import HipEngine, build_config
+    from gigaam_amd.feeder import collate
+    gdir = os.path.join(ROOT, "tests", "golden")
+    meta = json.load(open(os.path.join(gdir, "fullsize_meta.json")))["fullsize_v2_ctc_longform"]
+    gold = dict(np.load(os.path.join(gdir, "fullsize_v2_ctc_longform.npz")))
+    segs, _ = workloads.config5_segments(3600)
+    assert len(segs) == meta["n_chunks"]
+    audio = workloads.config5_audio(3600)
+    o0 = int(meta["strict_window_offset_s"] * 16000)
+    chunks = [audio[o0: o0 + int(meta["strict_window_s"] * 16000)]] + [segs[i] for i in meta["chunk_index"][1:]]
+    wav, wlen = collate(chunks)
+    assert wlen.tolist() == gold["wav_len"].tolist()
+    ck = synth.make_checkpoint("v2_ctc", seed=0)
+    cfg = ck["cfg"]
+    eng = HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], cfg["head"]), ck["state_dict"], torch.device("cuda:0"))
+    enc, elen = eng.encode(*eng.frontend(wav, wlen))
+    assert elen.cpu().tolist() == gold["enc_len"].tolist() == [751, 550, 546]
+    err = float((enc.cpu()[:, ::16, ::5] - torch.from_numpy(gold["enc_probe"])).abs().max())
+    report("fullsize_encoder_vs_reference", case="fullsize_v2_ctc_longform", err=err, tol=2e-4, min_margin=meta["min_margin"])
+    assert err < 2e-4, err
+    assert ragged_from_device(*eng.ctc_greedy(enc, elen)) == _ref_ragged(gold)
