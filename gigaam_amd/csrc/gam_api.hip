@@ -312,8 +312,20 @@ int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls
     if (w16->sp == nullptr) return fail(h, -2, "sp32 A without sp32 W planes");
     a.Whi = w16->hi; a.Wlo = w16->lo; a.wscale_inv = w16->inv;
     a.Wsp = w16->sp;
+    const GamSpPlan plan = gam_gemm_sp_plan(a.M, a.N, a.K, a.a_mode, h->ncu);
+    a.sp_mt = plan.mt; a.sp_nw = plan.nw;
+    GamGemmArgs full = a;
+    if (plan.s > 1) {   // small grid: S slices of K leave partial sums, the reduce pass applies the epilogue
+      if (int r = ensure(h, h->splitk_ws, (size_t)plan.s * a.M * a.N + 64)) return r;
+      a.splitk = plan.s; a.partial = h->splitk_ws.p;
+    }
     e = gam_launch_gemm_sp(a, act, s);
     if (e != hipSuccess) return fail(h, -2, "sp gemm launch (M=%d N=%d K=%d): %s", a.M, a.N, a.K, hipGetErrorString(e));
+    if (plan.s > 1) {
+      full.partial = a.partial;
+      e = gam_launch_splitk_reduce(full, act, plan.s, s);
+      if (e != hipSuccess) return fail(h, -2, "split-K reduce launch (M=%d N=%d): %s", a.M, a.N, hipGetErrorString(e));
+    }
     return 0;
   }
   if (a.Asp != nullptr) return fail(h, -2, "sp32 A operand outside the split-fp16 GEMM mode");
@@ -1370,6 +1382,11 @@ int gam_range_flag_fetch(gam_handle* h, int32_t* flag_dev, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   HIPCHK(h, hipMemcpyAsync(flag_dev, h->range_flag, sizeof(int), hipMemcpyDeviceToDevice, s));
   HIPCHK(h, hipMemsetAsync(h->range_flag, 0, sizeof(int), s));
+  return 0;
+}
+
+int gam_tune_sp(int mt, int nw, int splitk) {
+  g_gam_sp_force[0] = mt; g_gam_sp_force[1] = nw; g_gam_sp_force[2] = splitk;
   return 0;
 }
 

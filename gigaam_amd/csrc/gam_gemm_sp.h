@@ -52,7 +52,8 @@
 #define GAM_SP_TL(i)
 #endif
 
-#define GAM_SP_MIN_M 2048   // below this the 128x128 kernels fill the chip better
+#define GAM_SP_MIN_M 1      // rows from which the encoder runs on this kernel family: all (with split-K for small grids it beats the
+                            // 128x128 register-staged kernels from one 5 s clip up, profiles/r03_smallm_sweep.txt); GAM_SP_MIN_M overrides
 
 template <int MT, int NW>
 struct GamGemmSpCfg {
@@ -127,9 +128,18 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = g.K / 32;
-  // next k-tile to fetch, tracked incrementally (no divisions in the loop); it stops at the last tile
-  int d_kt = 0, d_c0 = 0, d_kw = 0, d_kh = 0;
+  // split-K (grid.y = g.splitk slices, small grids: a few utterances per GPU): this workgroup contracts k-tiles
+  // [kt_first, kt_first + nk) and leaves raw partial sums in g.partial[slice]; gam_splitk_reduce_kernel sums the slices in
+  // a fixed order (bit-reproducible) and applies the epilogue.  One slice = the whole K = the plain kernel.
+  const int nslice = g.splitk > 1 ? g.splitk : 1;
+  const int nk = g.K / 32 / nslice;
+  const int kt_first = (nslice > 1 ? (int)blockIdx.y : 0) * nk, kt_end = kt_first + nk;
+  // next k-tile to fetch, tracked incrementally (no divisions in the loop); it stops at the slice's last tile
+  int d_kt = kt_first, d_c0 = 0, d_kw = 0, d_kh = 0;
+  if (g.a_mode != 0) {   // taps innermost: k-tile = 9 * (32-channel block) + 3 kh + kw
+    const int cb = kt_first / 9, t9 = kt_first - cb * 9;
+    d_c0 = 32 * cb; d_kh = t9 / 3; d_kw = t9 - d_kh * 3;
+  }
   auto dma_ka = [&]() -> size_t {   // byte offset of tile d_kt along an A row
     if (g.a_mode == 0) return (size_t)d_kt * 128;
     return (((size_t)d_kh * g.conv_fp + d_kw) * (size_t)g.conv_c + d_c0) * 4;
@@ -138,7 +148,7 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
   // + 1) pixel patch of the tile, shifted -- 139 KB per workgroup, L2-resident -- instead of streaming the whole
   // 768-channel image once per tap (the weight's sp32 copy is laid out in the same k-tile order, make_split)
   auto dma_advance = [&]() {
-    if (d_kt + 1 >= nk) return;
+    if (d_kt + 1 >= kt_end) return;
     ++d_kt;
     if (g.a_mode == 0) return;
     if (++d_kw == 3) {
@@ -313,9 +323,21 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
         orow = (long)bb * g.out_rpb + tt + g.out_shift;
       }
     }
-    if (skip) continue;
+    if (skip && g.partial == nullptr) continue;
     // per-row factor (weight scale x the A operand's row scale)
     const float rsc = accscale * (g.a_rs != nullptr ? g.a_rs[row] : 1.0f);
+    if (g.partial != nullptr) {   // split-K slice: scaled raw sums; bias / activation / residual belong to the reduce pass
+      float* P = g.partial + ((size_t)blockIdx.y * (size_t)g.M + (size_t)row) * (size_t)g.N;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int ecol = nw + 32 * j + 8 * q + lq;
+          if (ecol < g.N)
+            *reinterpret_cast<f32x4*>(P + ecol) = (f32x4){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} * rsc;
+        }
+      continue;
+    }
     f32x4 rv[2][4];
     if (g.R != nullptr) {   // all eight residual pieces of the row in flight before the first use
 #pragma unroll
@@ -371,32 +393,59 @@ static inline void gam_launch_gemm_sp_t(const GamGemmArgs& a, int grid, hipStrea
   constexpr int smem = GamGemmSpCfg<MT, NW>::SMEM;
   auto kern = gam_gemm_sp_kernel<ACT, MT, NW>;
   if (gam_set_max_lds(reinterpret_cast<const void*>(kern), smem, attr_devs) != hipSuccess) return;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * NW), smem, stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(128 * NW), smem, stream, a);
 }
 
-// Tile shape.  NW = 4: (64 MT) x 256 tiles, 8 waves, one workgroup per CU -- fewest bytes per FLOP.
-// NW = 2: (64 MT) x 128 tiles, 4 waves, two workgroups per CU -- twice the tiles, for grids that
-// would leave CUs idle.  Cost model (units: MFMA work of a 64 x 256 strip): the busiest CU runs
-// ceil(tiles / CUs) tiles of MT * NW/4 units plus a fixed share per tile (prologue, epilogue);
-// measured at M = 16064 / 4016 it ranks the six shapes the way the sweep did
-// (e.g. N = 768: 84 x 3 tiles of 192 x 256 = 0.98 rounds beat 63 x 3 of 256 x 256 = 0.74).
-static inline void gam_gemm_sp_pick(int M, int N, int K, int& mt, int& nw, int ncu = 256) {
-  static int f_mt = -1, f_nw = -1;
-  if (f_mt < 0) { const char* e = getenv("GAM_SP_MT"); f_mt = e ? atoi(e) : 0; }
-  if (f_nw < 0) { const char* e = getenv("GAM_SP_NW"); f_nw = e ? atoi(e) : 0; }
-  (void)K;
-  double best = 1e30;
-  mt = 3; nw = 4;
+// Tile shape and split-K factor.  NW = 4: (64 MT) x 256 tiles, 8 waves, one workgroup per CU -- fewest bytes per FLOP.
+// NW = 2: (64 MT) x 128 tiles, 4 waves, up to two workgroups per CU.  S > 1: the K range is cut into S slices (grid.y) whose
+// partial sums a second pass adds up -- for grids that would leave most of the chip idle (a few utterances per GPU: the
+// strong-scaling points, single clips).  The plan minimises a time model fitted to the sweep of tools/smallm_sweep.py
+// (profiles/r03_smallm_sweep.txt): the busiest CU runs ceil(workgroups / slots) workgroups of
+//   nk / S k-tiles x t_kt(MT, NW, sharing) + t_fix(NW, S > 1),    plus, for S > 1, the reduce pass over (S + 1) M N floats.
+struct GamSpPlan { int mt, nw, s; };
+static int g_gam_sp_force[3] = {-1, -1, -1};    // tuning hook (gam_tune_sp / GAM_SP_MT, GAM_SP_NW, GAM_SP_SPLITK): 0 = free
+static inline double gam_gemm_sp_model(int M, int N, int K, int a_mode, int t, int w, int S, int ncu) {
+  const long wgs = (long)gam_cdiv(M, 64 * t) * gam_cdiv(N, 64 * w) * S;
+  const int nkt = K / 32 / S;
+  double t_kt, t_fix, rounds;
+  if (w == 4) {
+    t_kt = 0.50 * t + 0.03;                       // us per k-tile, one 8-wave workgroup per CU
+    t_fix = S > 1 ? 5.0 : 8.0;                    // prologue + epilogue (partial sums: no bias / residual / split)
+    rounds = (double)((wgs + ncu - 1) / ncu);
+  } else {
+    const bool shared = wgs > ncu;                // two 4-wave workgroups on a CU run ~1.6x slower each
+    t_kt = (0.40 * t + 0.20) * (shared ? 1.6 : 1.0);
+    t_fix = (S > 1 ? 4.0 : 6.0) * (shared ? 1.3 : 1.0);
+    rounds = (double)((wgs + (shared ? 2 : 1) * ncu - 1) / ((shared ? 2 : 1) * ncu));
+  }
+  if (a_mode != 0) t_kt *= 1.05;
+  double us = rounds * (nkt * t_kt + t_fix);
+  if (S > 1) us += 3.5 + (double)(S + 2) * M * N * 4.0 / 3.0e6;   // launch + partials read, residual read, C write at ~3 TB/s
+  return us;
+}
+static inline GamSpPlan gam_gemm_sp_plan(int M, int N, int K, int a_mode = 0, int ncu = 256) {
+  if (g_gam_sp_force[0] < 0) {
+    const char* e0 = getenv("GAM_SP_MT"); const char* e1 = getenv("GAM_SP_NW"); const char* e2 = getenv("GAM_SP_SPLITK");
+    g_gam_sp_force[0] = e0 ? atoi(e0) : 0; g_gam_sp_force[1] = e1 ? atoi(e1) : 0; g_gam_sp_force[2] = e2 ? atoi(e2) : 0;
+  }
+  const int f_mt = g_gam_sp_force[0], f_nw = g_gam_sp_force[1], f_s = g_gam_sp_force[2];
+  GamSpPlan best = {3, 4, 1};
+  double bt = 1e30;
+  const int nk = K / 32;
   for (int w = 4; w >= 2; w -= 2) {
     if ((f_nw == 2 || f_nw == 4) && w != f_nw) continue;
     for (int t = (w == 2 ? 3 : 4); t >= 2; --t) {
       if (f_mt >= 2 && f_mt <= 4 && t != f_mt && !(w == 2 && f_mt == 4)) continue;
-      const long tiles = (long)gam_cdiv(M, 64 * t) * gam_cdiv(N, 64 * w);
-      const double per_cu = (double)((tiles + ncu - 1) / ncu);
-      const double cost = per_cu * (t * (w / 4.0) + (w == 4 ? 0.6 : 0.45));
-      if (cost < best - 1e-9) { best = cost; mt = t; nw = w; }
+      for (int S = 1; S <= 16; ++S) {
+        if (f_s >= 1 && S != f_s) continue;
+        if (S > 1 && (nk % S != 0 || nk / S < 4)) continue;     // whole k-tiles, and enough of them to fill the two-stage pipeline
+        if (f_s < 1 && S > 1 && (long)gam_cdiv(M, 64 * t) * gam_cdiv(N, 64 * w) * 2 > ncu) continue;   // only for grids under half the chip
+        const double us = gam_gemm_sp_model(M, N, K, a_mode, t, w, S, ncu);
+        if (us < bt - 1e-9) { bt = us; best = {t, w, S}; }
+      }
     }
   }
+  return best;
 }
 
 static inline hipError_t gam_launch_gemm_sp(const GamGemmArgs& a_in, int act, hipStream_t stream) {
@@ -405,8 +454,15 @@ static inline hipError_t gam_launch_gemm_sp(const GamGemmArgs& a_in, int act, hi
   if (a.K <= 0 || a.K % 32 != 0 || a.Asp == nullptr || a.Wsp == nullptr) return hipErrorInvalidValue;
   if (a.a_mode == 0 ? (a.lda % 32 != 0) : (a.conv_c % 32 != 0)) return hipErrorInvalidValue;
   if (!gam_gemm_sp_epilogue_ok(a)) return hipErrorInvalidValue;
-  int mt, nw;
-  gam_gemm_sp_pick(a.M, a.N, a.K, mt, nw);
+  // the caller made the plan (it owns the split-K workspace): a.sp_mt / a.sp_nw / a.splitk (+ a.partial when > 1)
+  int mt = a.sp_mt, nw = a.sp_nw;
+  if (mt < 2 || mt > 4 || (nw != 2 && nw != 4) || (nw == 2 && mt == 4)) {
+    const GamSpPlan p = gam_gemm_sp_plan(a.M, a.N, a.K, a.a_mode);
+    mt = p.mt; nw = p.nw;
+    if (a.splitk > 1 && a.partial == nullptr) return hipErrorInvalidValue;
+  }
+  if (a.splitk > 1 && (a.partial == nullptr || (a.K / 32) % a.splitk != 0)) return hipErrorInvalidValue;
+  if (a.splitk <= 1) { a.splitk = 0; a.partial = nullptr; }
   const int grid = gam_cdiv(a.M, 64 * mt) * gam_cdiv(a.N, 64 * nw);
   a.ntiles = grid;
   static int dbg = -1, prio = -1;

@@ -151,6 +151,10 @@ int gam_op_gemm(gam_handle* h, const float* A, const float* W, const float* bias
 int gam_op_attention(gam_handle* h, const float* q, const float* k, const float* v, float* ctx,
                      const int32_t* lens, int B, int T, int H, void* stream);
 
+/* Tuning hook of the large-M GEMM (tools/smallm_sweep.py): force the tile shape (mt in 2..4 rows of 64, nw in {2, 4}
+ * columns of 64) and / or the split-K factor of every following launch in this process; 0 = planned per launch (default). */
+int gam_tune_sp(int mt, int nw, int splitk);
+
 /* Per-kernel-class HIP-event timing on the launch stream (bench.py's roofline leg).
  * gam_profile_enable(h,1) starts collecting for every launch, (h,2) for the GEMM family only
  * (fewer event packets inside a timed region), (h,0) stops; gam_profile_read synchronises the events and

@@ -20,21 +20,20 @@ MODES = ["f16x3", "f16x3-sp", "f32"]
 
 
 def _make_engine(cfg, state_dict, mode, head=True):
+    """mode "f16x3": the 128x128 register-staged split-fp16 kernels (forced: the product runs the LDS-DMA family at every
+    size since r03); "f16x3-sp": the LDS-DMA sp32 family (the product's default); "f32": exact-fp32 MFMA."""
     import os
     from gigaam_amd.engine import HipEngine, build_config
-    sp = mode.endswith("-sp")
     old = os.environ.get("GAM_SP_MIN_M")
-    if sp:
-        os.environ["GAM_SP_MIN_M"] = "1"   # read when the handle is created
+    os.environ["GAM_SP_MIN_M"] = "1" if mode.endswith("-sp") else str(1 << 30)   # read when the handle is created
     try:
         eng = HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], cfg.get("head") if head else None), state_dict,
                         torch.device("cuda:0"))
     finally:
-        if sp:
-            if old is None:
-                del os.environ["GAM_SP_MIN_M"]
-            else:
-                os.environ["GAM_SP_MIN_M"] = old
+        if old is None:
+            del os.environ["GAM_SP_MIN_M"]
+        else:
+            os.environ["GAM_SP_MIN_M"] = old
     eng.set_gemm_mode(mode.split("-")[0])
     assert eng.gemm_mode == mode.split("-")[0]
     return eng
