@@ -111,6 +111,7 @@ struct gam_handle {
   int sp_min_m = GAM_SP_MIN_M;   // GAM_SP_MIN_M overrides (tests force the sp path at small sizes)
   DevBuf op_planes, op_sp, splitk_ws;   // gam_op_gemm operand planes; split-K partial sums
   int use_splitk = 1;   // GAM_SPLITK=0 disables split-K for small grids
+  int fuse_reduce = 1;  // GAM_FUSE_REDUCE=0: the split-K reduce of a residual GEMM stays a kernel of its own (A/B switch)
   // hipGraph replay of the Conformer-layer launch sequence for small batches (launch-bound: a 5 s clip is
   // ~450 launches of 5-25 us).  Keyed on the shape; captured the second time a shape is seen (the first
   // call sizes every workspace and sets the kernel attributes); dropped whenever a workspace buffer moves.
@@ -295,8 +296,19 @@ struct ProfScope {
   }
 };
 
-int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls = GAM_PF_GEMM, const W16* w16 = nullptr) {
+// A split-K reduce left to the consumer: the LayerNorm that follows a residual GEMM sums the slices itself (gam_norm.h)
+struct PendingReduce {
+  const float* part = nullptr;
+  int nsplit = 0;
+  const float* bias = nullptr;
+  const float* resid = nullptr;
+  float alpha = 1.0f;
+};
+
+int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls = GAM_PF_GEMM, const W16* w16 = nullptr,
+         PendingReduce* defer = nullptr) {
   GamGemmArgs a = a_in;
+  if (defer) *defer = PendingReduce();
   a.range_flag = h->use_range ? h->range_flag : nullptr;
   if (h->gemm_mode != GAM_GEMM_F16X3) a.c_guard = 0;   // fp32 consumers have no range limit
   if (h->gemm_mode != GAM_GEMM_F16X3 || w16 == nullptr || w16->hi == nullptr) a.a_rs = nullptr;   // exact-fp32 path: A is never scaled
@@ -321,7 +333,10 @@ int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls
     }
     e = gam_launch_gemm_sp(a, act, s);
     if (e != hipSuccess) return fail(h, -2, "sp gemm launch (M=%d N=%d K=%d): %s", a.M, a.N, a.K, hipGetErrorString(e));
-    if (plan.s > 1) {
+    if (plan.s > 1 && defer != nullptr && h->fuse_reduce && act == GAM_ACT_NONE && !a.c_split && !a.c_guard && a.lens == nullptr &&
+        !a.remap && a.ldc == a.N && (a.R == nullptr || a.ldr == a.N)) {
+      defer->part = a.partial; defer->nsplit = plan.s; defer->bias = a.bias; defer->resid = a.R; defer->alpha = a.alpha;
+    } else if (plan.s > 1) {
       full.partial = a.partial;
       e = gam_launch_splitk_reduce(full, act, plan.s, s);
       if (e != hipSuccess) return fail(h, -2, "split-K reduce launch (M=%d N=%d): %s", a.M, a.N, hipGetErrorString(e));
@@ -369,7 +384,11 @@ GamGemmArgs gemm_args(const float* A, long lda, const float* W, const float* bia
   return g;
 }
 
-int layernorm(gam_handle* h, hipStream_t s, GamLnArgs a, int mode) {
+int layernorm(gam_handle* h, hipStream_t s, GamLnArgs a, int mode, const PendingReduce* pend = nullptr) {
+  if (pend != nullptr && pend->part != nullptr) {
+    a.part = pend->part; a.nsplit = pend->nsplit; a.pbias = pend->bias; a.presid = pend->resid; a.palpha = pend->alpha;
+    a.xstore = const_cast<float*>(a.x);
+  }
   const double bytes = (double)a.rows * a.d * 4.0 * (mode == 0 ? 2.0 : 3.0);
   ProfScope ps(h, s, GAM_PF_NORM, bytes);
   hipError_t e = gam_launch_layernorm(a, mode, s);
@@ -397,6 +416,7 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   if (const char* e = getenv("GAM_SP")) h->use_sp = atoi(e);
   if (const char* e = getenv("GAM_SP_MIN_M")) h->sp_min_m = atoi(e);
   if (const char* e = getenv("GAM_SPLITK")) h->use_splitk = atoi(e);
+  if (const char* e = getenv("GAM_FUSE_REDUCE")) h->fuse_reduce = atoi(e);
   if (const char* e = getenv("GAM_GRAPH")) h->use_graph = atoi(e);
   if (const char* e = getenv("GAM_RNNT_CLUSTER")) h->rnnt_cluster = atoi(e);
   if (const char* e = getenv("GAM_RNNT_COOP")) h->rnnt_coop = atoi(e);
@@ -956,6 +976,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     a.split1 = sp;
     if (int r = layernorm(h, s, a, 0)) return r;
   }
+  PendingReduce pend;    // the split-K slices of the residual GEMM just launched, summed by the LayerNorm that follows it
   for (int li = 0; li < nl; ++li) {
     const LayerW& L = h->layers[li];
     // --- FFN 1 (macaron half step) ---
@@ -966,14 +987,14 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff1_w2, L.ff1_b2, h->x.p, D, N, D, DFF);
       g2.R = h->x.p; g2.ldr = D; g2.alpha = 0.5f;
       sp_a(g2);
-      if (int r = gemm(h, s, g2, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_ff1_w2)) return r;
+      if (int r = gemm(h, s, g2, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_ff1_w2, &pend)) return r;
     }
     // --- self attention ---
     {
       GamLnArgs a = ln;
       a.x = h->x.p; a.out1 = h->y.p; a.out2 = h->yr.p; a.w1 = L.ln_att_w; a.b1 = L.ln_att_b;
       a.split1 = sp; a.split2 = sp;
-      if (int r = layernorm(h, s, a, rel ? 0 : 1)) return r;
+      if (int r = layernorm(h, s, a, rel ? 0 : 1, &pend)) return r;
       // rotary: q,k project the rotated copy, v the plain one; rel_pos: all three project y
       GamGemmArgs gq = gemm_args(rel ? h->y.p : h->yr.p, D, L.wqk, L.bqk, h->qk.p, 2 * D, N, 2 * D, D);
       sp_a(gq); gq.a_rs = rs; gq.c_guard = 1;   // q, k and v are split to fp16 unscaled by the attention kernel
@@ -1001,14 +1022,14 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       GamGemmArgs go = gemm_args(h->ctx.p, D, L.wo, L.bo, h->x.p, D, N, D, D);
       go.R = h->x.p; go.ldr = D;
       sp_a(go);
-      if (int r = gemm(h, s, go, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wo)) return r;
+      if (int r = gemm(h, s, go, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wo, &pend)) return r;
     }
     // --- convolution module ---
     {
       GamLnArgs a = ln;
       a.x = h->x.p; a.out1 = h->y.p; a.w1 = L.ln_conv_w; a.b1 = L.ln_conv_b;
       a.split1 = sp;
-      if (int r = layernorm(h, s, a, 0)) return r;
+      if (int r = layernorm(h, s, a, 0, &pend)) return r;
       GamGemmArgs g1 = gemm_args(h->y.p, D, L.pw1_w, L.pw1_b, h->ubuf.p, 2 * D, N, 2 * D, D);
       sp_a(g1); g1.a_rs = rs;
       if (int r = gemm(h, s, g1, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_pw1)) return r;
@@ -1024,21 +1045,21 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       GamGemmArgs g2 = gemm_args(h->zbuf.p, D, L.pw2_w, L.pw2_b, h->x.p, D, N, D, D);
       g2.R = h->x.p; g2.ldr = D;
       sp_a(g2);
-      if (int r = gemm(h, s, g2, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_pw2)) return r;
+      if (int r = gemm(h, s, g2, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_pw2, &pend)) return r;
     }
     // --- FFN 2 ---
     {
       GamLnArgs a = ln;
       a.x = h->x.p; a.out1 = h->y.p; a.w1 = L.ln_ff2_w; a.b1 = L.ln_ff2_b;
       a.split1 = sp;
-      if (int r = layernorm(h, s, a, 0)) return r;
+      if (int r = layernorm(h, s, a, 0, &pend)) return r;
       GamGemmArgs g = gemm_args(h->y.p, D, L.ff2_w1, L.ff2_b1, h->hbuf.p, DFF, N, DFF, D);
       sp_a(g); g.c_split = sp; g.a_rs = rs; g.c_guard = 1;
       if (int r = gemm(h, s, g, GAM_ACT_SILU, GAM_PF_GEMM, &L.s_ff2_w1)) return r;
       GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff2_w2, L.ff2_b2, h->x.p, D, N, D, DFF);
       g2.R = h->x.p; g2.ldr = D; g2.alpha = 0.5f;
       sp_a(g2);
-      if (int r = gemm(h, s, g2, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_ff2_w2)) return r;
+      if (int r = gemm(h, s, g2, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_ff2_w2, &pend)) return r;
     }
     // --- norm_out (+ next layer's norm_feed_forward1) ---
     {
@@ -1047,10 +1068,10 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       if (li + 1 < nl) {
         a.out2 = h->y.p; a.w2 = h->layers[li + 1].ln_ff1_w; a.b2 = h->layers[li + 1].ln_ff1_b;
         a.split2 = sp;
-        if (int r = layernorm(h, s, a, 2)) return r;
+        if (int r = layernorm(h, s, a, 2, &pend)) return r;
       } else {
         a.rs = nullptr;   // the last norm_out feeds no GEMM
-        if (int r = layernorm(h, s, a, 0)) return r;
+        if (int r = layernorm(h, s, a, 0, &pend)) return r;
       }
     }
   }

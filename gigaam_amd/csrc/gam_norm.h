@@ -27,6 +27,16 @@ struct GamLnArgs {
   // stored multiplied by 2^e in either format (sp32 or fp32: these outputs feed GEMMs only).  null = no scaling.
   float* rs;
   int rope_rows;        // rows of rcos / rsin (pos_emb_max_len): the stride-padding rows of a row block clamp to it
+  // Fused split-K reduce (small grids: gam_gemm_sp.h split-K): instead of reading the row from x, build it from the
+  // producing GEMM's partial sums -- x_row = resid + alpha (sum_s part[s] + bias), summed in slice order like
+  // gam_splitk_reduce_kernel -- and store it to x (the residual stream) before normalising it.  One pass and one launch
+  // instead of reduce kernel + LayerNorm kernel.  part == nullptr: plain LayerNorm.
+  const float* part;    // [nsplit][rows][d] partial sums
+  int nsplit;
+  const float* pbias;   // [d] or null
+  const float* presid;  // [rows][d] or null
+  float palpha;
+  float* xstore;        // where the finished row goes (MODE 0 / 1; MODE 2 overwrites it with out1 anyway)
 };
 
 // max |v| of a row held as float4[GAM_LN_MAXJ] across a wave
@@ -76,10 +86,37 @@ __global__ __launch_bounds__(256) void gam_layernorm_kernel(GamLnArgs a) {
   const int row = live ? row_raw : a.rows - 1;
   const float* xr = a.x + (size_t)row * a.d;
   float4 v[GAM_LN_MAXJ];
+  if (a.part != nullptr) {   // fused split-K reduce: the row is finished here (see GamLnArgs)
+    const size_t slice = (size_t)a.rows * a.d;
 #pragma unroll
-  for (int j = 0; j < GAM_LN_MAXJ; ++j) {
-    const int c = (j * 64 + lane) * 4;
-    v[j] = c < a.d ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < GAM_LN_MAXJ; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < a.d) {
+        const float* pr = a.part + (size_t)row * a.d + c;
+        for (int sl = 0; sl < a.nsplit; ++sl) {
+          const float4 t = *reinterpret_cast<const float4*>(pr + sl * slice);
+          acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        if (a.pbias != nullptr) {
+          const float4 bb = *reinterpret_cast<const float4*>(a.pbias + c);
+          acc.x += bb.x; acc.y += bb.y; acc.z += bb.z; acc.w += bb.w;
+        }
+        acc.x *= a.palpha; acc.y *= a.palpha; acc.z *= a.palpha; acc.w *= a.palpha;
+        if (a.presid != nullptr) {
+          const float4 rr = *reinterpret_cast<const float4*>(a.presid + (size_t)row * a.d + c);
+          acc.x += rr.x; acc.y += rr.y; acc.z += rr.z; acc.w += rr.w;
+        }
+        if (live && MODE != 2) *reinterpret_cast<float4*>(a.xstore + (size_t)row * a.d + c) = acc;
+      }
+      v[j] = acc;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < GAM_LN_MAXJ; ++j) {
+      const int c = (j * 64 + lane) * 4;
+      v[j] = c < a.d ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
   gam_ln_row(v, a.d, lane, a.eps, a.w1, a.b1);
   float sc1 = 1.0f, sc2 = 1.0f;    // applied to the stored values of an sp32 output
