@@ -88,18 +88,35 @@ def make_gather(kind: str, rank: int, n_ranks: int, dev: torch.device):
     if n_ranks == 1:
         return (lambda index, counts, ids, frames: (index, counts, ids, frames)), "none (one rank)"
     if kind == "rccl":
-        def exchange(uid):
-            if n_ranks == 1:
-                return uid
-            box = [uid]
-            dist.broadcast_object_list(box, src=0)
-            return box[0]
-        try:
-            comm = shard.HipComm(rank, n_ranks, dev, exchange)
-            ok = 1
-        except Exception as e:   # the line must still be produced: fall back to torch's own RCCL group, and say so
-            print(f"[bench] rank {rank}: gam_comm_create failed ({e}); using torch.distributed for the gather", file=sys.stderr)
-            ok = 0
+        # the 128-byte RCCL id travels over torch.distributed's store, on the MAIN thread (a collective of the default group)
+        import ctypes as C
+        import threading
+        from gigaam_amd import _lib
+        buf = C.create_string_buffer(128)
+        rc0 = _lib.load_library().gam_comm_unique_id(buf) if rank == 0 else 0
+        sent = [buf.raw if (rank == 0 and rc0 == 0) else b""]
+        dist.broadcast_object_list(sent, src=0)
+        uid = sent[0]
+        # gam_comm_create (ncclCommInitRank behind the C ABI) has only ever run with a world of one on the builder's 1-GPU
+        # boxes: it gets a watchdog thread, so that a rendezvous that never completes costs this run its RCCL-behind-the-ABI
+        # gather, not its bench line (the ranks then agree, below, to use torch.distributed's own RCCL group).
+        box, ok = {}, 0
+
+        def create():
+            try:
+                torch.cuda.set_device(dev)       # (the current device is per thread)
+                box["comm"] = shard.HipComm(rank, n_ranks, dev, lambda _mine: uid)
+            except Exception as e:   # noqa: BLE001
+                box["err"] = e
+        th = threading.Thread(target=create, daemon=True)
+        th.start()
+        th.join(timeout=float(os.environ.get("GAM_COMM_TIMEOUT_S", "90")))
+        if th.is_alive():
+            print(f"[bench] rank {rank}: gam_comm_create did not return within the watchdog; using torch.distributed for the gather", file=sys.stderr)
+        elif "err" in box:   # the line must still be produced: fall back to torch's own RCCL group, and say so
+            print(f"[bench] rank {rank}: gam_comm_create failed ({box['err']}); using torch.distributed for the gather", file=sys.stderr)
+        else:
+            comm, ok = box["comm"], 1
         flag = torch.tensor([ok], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank takes the same path
         if int(flag.item()) == 1:

@@ -252,20 +252,30 @@ __global__ __launch_bounds__(256, GAM_ATT_NJ == 1 ? 4 : 2) void gam_attn_f16x3_k
       }
     }
 
-    // ---- key mask + online softmax (fp32, per query = per lane column) ----
+    // ---- key mask + online softmax (fp32, per query = per lane column).  Only the LAST key tile of an utterance can hold
+    //      keys >= klen: every other tile skips the compare + select per score (2 of the ~10 VALU instructions a score
+    //      costs in this VALU-bound kernel); the branch is workgroup-uniform.
+    const bool full_tile = kt0 + GAM_ATT_KT <= klen;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       float mx = -INFINITY;
+      if (full_tile) {
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt0 + kb * 16 + lg * 4 + r;
-          float s = st[kb][j][r];
-          s = key < klen ? s : -INFINITY;
-          st[kb][j][r] = s;
-          mx = fmaxf(mx, s);
-        }
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, st[kb][j][r]);
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt0 + kb * 16 + lg * 4 + r;
+            float s = st[kb][j][r];
+            s = key < klen ? s : -INFINITY;
+            st[kb][j][r] = s;
+            mx = fmaxf(mx, s);
+          }
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mnew = fmaxf(mrun[j], mx);   // finite: key kt0 < klen is in this tile
