@@ -24,6 +24,35 @@ class CTCHead(_EngineModule):
         return self.engine.ctc_head(encoder_output)
 
 
+class _HeadPart:
+    """``head.decoder`` / ``head.joint`` of the reference's RNNTHead (gigaam/decoder.py:24-149) as attribute views: the
+    constructor arguments under the reference's attribute names.  Their per-step entry points (``RNNTDecoder.predict``,
+    ``RNNTJoint.joint``) do not exist on this path -- the predictor, the joint and the greedy loop that calls them
+    (gigaam/decoding.py:128-207) are ONE launch per batch (``gam_rnnt_greedy``) -- and the only reference callers that
+    take these sub-modules apart are the ONNX export (model.py:183-192) and training (train_utils/module.py:130-144),
+    both outside this path: calling them says so instead of failing with an AttributeError."""
+
+    def __init__(self, kind: str, **cfg: int):
+        self._kind = kind
+        self.__dict__.update(cfg)
+
+    def _no_step(self, name: str):
+        raise NotImplementedError(
+            f"RNNTHead.{self._kind}.{name}: the MI355X path evaluates the predictor / joint inside gam_rnnt_greedy, one "
+            "launch per batch (RNNTGreedyDecoding.decode); there is no per-step entry point to export or train through")
+
+    def predict(self, *a, **k):
+        self._no_step("predict")
+
+    def joint(self, *a, **k):
+        self._no_step("joint")
+
+    def forward(self, *a, **k):
+        self._no_step("forward")
+
+    __call__ = forward
+
+
 class RNNTHead(_EngineModule):
     _prefix = "head."
 
@@ -31,6 +60,9 @@ class RNNTHead(_EngineModule):
         super().__init__()
         self.decoder_cfg = dict(decoder)
         self.joint_cfg = dict(joint)
+        # (plain objects, not nn.Modules: kept out of the module tree)
+        object.__setattr__(self, "decoder", _HeadPart("decoder", blank_id=self.decoder_cfg["num_classes"] - 1, **self.decoder_cfg))
+        object.__setattr__(self, "joint", _HeadPart("joint", **self.joint_cfg))
 
     def _cfg_trees(self):
         head: Dict[str, Any] = {"_target_": "RNNTHead", "decoder": self.decoder_cfg, "joint": self.joint_cfg}
