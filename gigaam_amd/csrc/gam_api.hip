@@ -97,6 +97,7 @@ struct gam_handle {
   float *jn_enc_w = nullptr, *jn_enc_b = nullptr, *jn_pred_t = nullptr, *jn_pred_b = nullptr;
   float *jn_out_w = nullptr, *jn_out_b = nullptr, *lstm_whh_t = nullptr, *lstm_tab = nullptr;
   float *lstm_whh_q = nullptr, *jn_pred_q = nullptr;   // [k/4][row][4] re-layouts for the cluster decode kernel
+  float *lstm_wih_x = nullptr, *lstm_whh_x = nullptr, *lstm_bias_x = nullptr;   // predictor layers above the first (gam_decode.h)
   int use_rowscale = 1;         // GAM_ROWSCALE=0: no per-row pre-scale of the LayerNorm-produced GEMM operands (A/B switch)
   int use_range = 1;            // GAM_RANGE=0: no range guard on the unscaled operands (A/B switch)
   int ncu = 256;                // compute units of the device (hipDeviceAttributeMultiprocessorCount)
@@ -440,7 +441,7 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   if (c.subsampling == GAM_SUBS_CONV1D && c.subs_kernel_size != 5) return fail(h, -1, "conv1d stem needs kernel 5");
   if (c.win_length != c.n_fft) return fail(h, -1, "win_length != n_fft unsupported");
   if (c.n_mels > 64 || c.n_mels != c.feat_in) return fail(h, -1, "n_mels %d / feat_in %d unsupported", c.n_mels, c.feat_in);
-  if (c.head_type == GAM_HEAD_RNNT && (c.pred_rnn_layers != 1 || c.pred_hidden > GAM_RNNT_MAXH || c.joint_hidden > GAM_RNNT_MAXH || c.num_classes > GAM_RNNT_MAXV || c.joint_hidden % 16 != 0 || c.pred_hidden % 16 != 0))
+  if (c.head_type == GAM_HEAD_RNNT && (c.pred_rnn_layers < 1 || c.pred_rnn_layers > 4 || c.pred_hidden > GAM_RNNT_MAXH || c.joint_hidden > GAM_RNNT_MAXH || c.num_classes > GAM_RNNT_MAXV || c.joint_hidden % 16 != 0 || c.pred_hidden % 16 != 0))
     return fail(h, -1, "RNN-T head shape unsupported");
   if (hipSetDevice(device_id) != hipSuccess) return fail(h, -2, "hipSetDevice(%d) failed", device_id);
   return 0;
@@ -780,6 +781,28 @@ int gam_finalize(gam_handle* h) {
       for (int k = 0; k < PH; ++k) whh_q[((size_t)(k / 4) * 4 * PH + r) * 4 + (k & 3)] = whh->data[(size_t)r * PH + k];
     for (int r = 0; r < JH; ++r)
       for (int k = 0; k < PH; ++k) wp_q[((size_t)(k / 4) * JH + r) * 4 + (k & 3)] = wp->data[(size_t)r * PH + k];
+    if (c.pred_rnn_layers > 1) {   // nn.LSTM layers 1 .. L-1 (decoder.py:78-83): transposed like W_hh, biases summed
+      const int LX = c.pred_rnn_layers - 1;
+      std::vector<float> wih_x((size_t)LX * PH * 4 * PH), whh_x((size_t)LX * PH * 4 * PH), bias_x((size_t)LX * 4 * PH);
+      for (int l = 1; l <= LX; ++l) {
+        const std::string sfx = "_l" + std::to_string(l);
+        NEED(wi, "head.decoder.lstm.weight_ih" + sfx, (int64_t)4 * PH * PH);
+        NEED(wh, "head.decoder.lstm.weight_hh" + sfx, (int64_t)4 * PH * PH);
+        NEED(bi, "head.decoder.lstm.bias_ih" + sfx, 4 * PH);
+        NEED(bh, "head.decoder.lstm.bias_hh" + sfx, 4 * PH);
+        const size_t o = (size_t)(l - 1) * PH * 4 * PH;
+        for (int r = 0; r < 4 * PH; ++r) {
+          for (int k = 0; k < PH; ++k) {
+            wih_x[o + (size_t)k * 4 * PH + r] = wi->data[(size_t)r * PH + k];
+            whh_x[o + (size_t)k * 4 * PH + r] = wh->data[(size_t)r * PH + k];
+          }
+          bias_x[(size_t)(l - 1) * 4 * PH + r] = bi->data[r] + bh->data[r];
+        }
+      }
+      UP(h->lstm_wih_x, wih_x);
+      UP(h->lstm_whh_x, whh_x);
+      UP(h->lstm_bias_x, bias_x);
+    }
     UP(h->lstm_whh_q, whh_q);
     UP(h->jn_pred_q, wp_q);
     UP(h->lstm_tab, tab);
@@ -1208,6 +1231,7 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
   a.bpred = h->jn_pred_b; a.wout = h->jn_out_w; a.bout = h->jn_out_b; a.ids = ids; a.frames = frames; a.counts = counts;
   a.dump = logits_dump; a.dump_count = dump_count; a.B = B; a.Tp = (int)Tp; a.V = c.num_classes; a.H = c.pred_hidden; a.JH = JH;
   a.max_symbols = max_symbols; a.cap = (int)Tp * max_symbols; a.dump_cap = logits_dump ? dump_cap : 0;
+  a.L = c.pred_rnn_layers; a.wih_x = h->lstm_wih_x; a.whh_x = h->lstm_whh_x; a.bias_x = h->lstm_bias_x;
   ProfScope ps(h, s, GAM_PF_DECODE, 0.0);
   // One workgroup per utterance (gam_decode.h): the whole decode when the cluster kernel does not take the shape
   // (GAM_RNNT_CLUSTER=0, a refused cooperative launch), and -- with only_failed -- the REPAIR pass behind every cluster
@@ -1217,8 +1241,8 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
   auto launch_single = [&](int only_failed) -> int {
     GamRnntArgs f = a;
     f.only_failed = only_failed;
-    f.wout_in_lds = gam_rnnt_smem(f.H, f.JH, f.V, 1) <= 96 * 1024 ? 1 : 0;
-    const size_t sm1 = gam_rnnt_smem(f.H, f.JH, f.V, f.wout_in_lds);
+    f.wout_in_lds = gam_rnnt_smem(f.H, f.JH, f.V, 1, f.L) <= 96 * 1024 ? 1 : 0;
+    const size_t sm1 = gam_rnnt_smem(f.H, f.JH, f.V, f.wout_in_lds, f.L);
     static std::atomic<unsigned long long> attr5{0}, attr8{0};
     HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_rnnt_greedy_kernel<5>), 160 * 1024, attr5));
     HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_rnnt_greedy_kernel<8>), 160 * 1024, attr8));
@@ -1237,7 +1261,7 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
     int C = (h->ncu - 16) / (8 * nu8);
     C = C > 8 ? 8 : C;
     if (h->rnnt_cluster >= 0) C = h->rnnt_cluster < C ? h->rnnt_cluster : C;
-    if (C >= 1 && JH % 16 == 0 && a.H % 4 == 0) {   // (JH % 16: MFMA k-steps and the LDS-DMA window)
+    if (C >= 1 && JH % 16 == 0 && a.H % 4 == 0 && a.L == 1) {   // (JH % 16: MFMA k-steps and the LDS-DMA window; L > 1: one-workgroup kernel)
       GamRnntClusterArgs ca;
       memset(&ca, 0, sizeof ca);
       ca.a = a; ca.whh_q = h->lstm_whh_q; ca.wpred_q = h->jn_pred_q; ca.C = C;

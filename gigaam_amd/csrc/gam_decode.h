@@ -109,6 +109,12 @@ struct GamRnntArgs {
   int B, Tp, V, H, JH, max_symbols, cap, dump_cap;
   int wout_in_lds;       // set by the launcher: W_out (V x JH fp32) is cached in LDS
   int only_failed;       // repair pass behind the cluster kernel: decode only the utterances it left at counts[b] < 0
+  // Predictor layers above the first (nn.LSTM(pred_hidden, pred_hidden, pred_rnn_layers), reference decoder.py:78-83): layer l
+  // takes the layer below's NEW hidden state as input.  L = 1 for every published checkpoint; L > 1 runs on this kernel only.
+  int L;
+  const float* wih_x;    // [L-1][H][4H]  weight_ih_l{1..} transposed
+  const float* whh_x;    // [L-1][H][4H]  weight_hh_l{1..} transposed
+  const float* bias_x;   // [L-1][4H]     bias_ih + bias_hh
 };
 
 #define GAM_RNNT_MAXH 512
@@ -116,10 +122,11 @@ struct GamRnntArgs {
 #define GAM_RNNT_MAXV 2048
 #define GAM_RNNT_WIN 16
 
-static inline size_t gam_rnnt_smem(int H, int JH, int V, int wout_in_lds) {
+static inline size_t gam_rnnt_smem(int H, int JH, int V, int wout_in_lds, int L = 1) {
   const int vp = (V + 15) / 16 * 16;
   size_t f = (size_t)8 * H + 2 * JH + (size_t)GAM_RNNT_WIN * (JH + 4) + (size_t)GAM_RNNT_WIN * (vp + 1) + 64 + 16;
   if (wout_in_lds) f += (size_t)V * (JH + 4);
+  f += (size_t)(L > 1 ? L - 1 : 0) * 4 * H;   // (h, c, h', c') of the predictor layers above the first
   return sizeof(float) * f;
 }
 
@@ -141,6 +148,9 @@ __global__ __launch_bounds__(256) void gam_rnnt_greedy_kernel(GamRnntArgs a) {
   float* lse_s = mx_s + GAM_RNNT_WIN;                              // [WIN]
   const int WLD = JH + 4;
   float* wout_l = a.wout_in_lds ? lse_s + GAM_RNNT_WIN + 12 : nullptr;   // [V][WLD], 16-byte aligned
+  // state of layers 1 .. L-1, behind everything else: layer l at xs + (l - 1) * 4H as [h | c | h' | c']
+  float* xs = lse_s + GAM_RNNT_WIN + 12 + (a.wout_in_lds ? (size_t)V * WLD : 0);
+  const int L = a.L > 1 ? a.L : 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg4 = lane >> 4;
   const int b = blockIdx.x;
@@ -149,6 +159,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_greedy_kernel(GamRnntArgs a) {
   len = len < 0 ? 0 : (len > a.Tp ? a.Tp : len);
 
   for (int i = tid; i < H; i += 256) { h_s[i] = 0.f; c_s[i] = 0.f; }
+  for (int i = tid; i < (L - 1) * 4 * H; i += 256) xs[i] = 0.f;
   if (wout_l != nullptr)
     for (int i = tid; i < V * JH; i += 256) wout_l[(i / JH) * WLD + (i % JH)] = a.wout[i];
   __syncthreads();
@@ -184,32 +195,49 @@ __global__ __launch_bounds__(256) void gam_rnnt_greedy_kernel(GamRnntArgs a) {
           roff[j] = tid + 256 * j < 4 * H ? tid + 256 * j : 4 * H - 1;
           acc[j] = a.gate_tab[(size_t)label * 4 * H + roff[j]];
         }
-        for (int k0 = 0; k0 < H; k0 += 16) {          // H % 16 == 0 (checked at gam_create)
-          float w[16][NR];
+        // acc[row] += sum_k Wt[k][row] vec[k]
+        auto matvec = [&](const float* __restrict__ wt, const float* vec) {
+          for (int k0 = 0; k0 < H; k0 += 16) {          // H % 16 == 0 (checked at gam_create)
+            float w[16][NR];
 #pragma unroll
-          for (int kk = 0; kk < 16; ++kk)
+            for (int kk = 0; kk < 16; ++kk)
 #pragma unroll
-            for (int j = 0; j < NR; ++j) w[kk][j] = a.whh_t[(size_t)(k0 + kk) * 4 * H + roff[j]];
+              for (int j = 0; j < NR; ++j) w[kk][j] = wt[(size_t)(k0 + kk) * 4 * H + roff[j]];
 #pragma unroll
-          for (int kk = 0; kk < 16; ++kk) {
-            const float hk = h_s[k0 + kk];
+            for (int kk = 0; kk < 16; ++kk) {
+              const float hk = vec[k0 + kk];
 #pragma unroll
-            for (int j = 0; j < NR; ++j) acc[j] = fmaf(w[kk][j], hk, acc[j]);
+              for (int j = 0; j < NR; ++j) acc[j] = fmaf(w[kk][j], hk, acc[j]);
+            }
           }
-        }
+        };
+        auto cell = [&](const float* c_old, float* h_new, float* c_new) {   // gates (i, f, g, o) -> (h', c')
 #pragma unroll
-        for (int j = 0; j < NR; ++j)
-          if (tid + 256 * j < 4 * H) gates[tid + 256 * j] = acc[j];
+          for (int j = 0; j < NR; ++j)
+            if (tid + 256 * j < 4 * H) gates[tid + 256 * j] = acc[j];
+          __syncthreads();
+          for (int i = tid; i < H; i += 256) {
+            const float ig = gam_sigmoid_exact(gates[i]), fg = gam_sigmoid_exact(gates[H + i]);
+            const float gg = tanhf(gates[2 * H + i]), og = gam_sigmoid_exact(gates[3 * H + i]);
+            const float cn = fg * c_old[i] + ig * gg;
+            c_new[i] = cn;
+            h_new[i] = og * tanhf(cn);
+          }
+          __syncthreads();
+        };
+        matvec(a.whh_t, h_s);
+        cell(c_s, hn_s, cn_s);
+        for (int l = 1; l < L; ++l) {     // layers above the first: input = the NEW hidden state of the layer below
+          float* st = xs + (size_t)(l - 1) * 4 * H;
+          const float* below = l == 1 ? hn_s : xs + (size_t)(l - 2) * 4 * H + 2 * H;
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[j] = a.bias_x[(size_t)(l - 1) * 4 * H + roff[j]];
+          matvec(a.wih_x + (size_t)(l - 1) * H * 4 * H, below);
+          matvec(a.whh_x + (size_t)(l - 1) * H * 4 * H, st);
+          cell(st + H, st + 2 * H, st + 3 * H);
+        }
       }
-      __syncthreads();
-      for (int i = tid; i < H; i += 256) {
-        const float ig = gam_sigmoid_exact(gates[i]), fg = gam_sigmoid_exact(gates[H + i]);
-        const float gg = tanhf(gates[2 * H + i]), og = gam_sigmoid_exact(gates[3 * H + i]);
-        const float cn = fg * c_s[i] + ig * gg;
-        cn_s[i] = cn;
-        hn_s[i] = og * tanhf(cn);
-      }
-      __syncthreads();
+      const float* gtop = L > 1 ? xs + (size_t)(L - 2) * 4 * H + 2 * H : hn_s;   // g = the top layer's new hidden state
       {
         float acc0 = tid < JH ? a.bpred[tid] : 0.f, acc1 = tid + 256 < JH ? a.bpred[tid + 256] : 0.f;
         const int r0 = tid < JH ? tid : JH - 1, r1 = tid + 256 < JH ? tid + 256 : JH - 1;
@@ -223,7 +251,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_greedy_kernel(GamRnntArgs a) {
           }
 #pragma unroll
           for (int kk = 0; kk < 32; ++kk) {
-            const float gk = k0 + kk < H ? hn_s[k0 + kk] : 0.f;
+            const float gk = k0 + kk < H ? gtop[k0 + kk] : 0.f;
             acc0 = fmaf(w0[kk], gk, acc0);
             acc1 = fmaf(w1[kk], gk, acc1);
           }
@@ -345,6 +373,10 @@ __global__ __launch_bounds__(256) void gam_rnnt_greedy_kernel(GamRnntArgs a) {
       ++sym;
       label = k;
       for (int i = tid; i < H; i += 256) { h_s[i] = hn_s[i]; c_s[i] = cn_s[i]; }
+      for (int i = tid; i < (L - 1) * 2 * H; i += 256) {   // commit (h', c') of the layers above the first
+        const int l1 = i / (2 * H), r = i - l1 * 2 * H;
+        xs[(size_t)l1 * 4 * H + r] = xs[(size_t)l1 * 4 * H + 2 * H + r];
+      }
       need_pred = true;
       if (sym >= a.max_symbols) { t = te + 1; sym = 0; }   // frame advances regardless (decoding.py:189-205)
       else t = te;

@@ -318,9 +318,12 @@ def load_calib(cfg: Dict[str, Any], seed: int) -> Optional[torch.Tensor]:
 
 
 def make_checkpoint(model_name: str, seed: int = 0, calib="auto", rnnt_blank_bias: Optional[float] = None,
-                    **encoder_overrides: Any) -> Dict[str, Any]:
-    """``calib``: "auto" = committed vector if there is one, None = zeros, or a tensor."""
+                    pred_rnn_layers: Optional[int] = None, **encoder_overrides: Any) -> Dict[str, Any]:
+    """``calib``: "auto" = committed vector if there is one, None = zeros, or a tensor.  ``pred_rnn_layers`` overrides the
+    RNN-T predictor's LSTM depth (every published checkpoint uses 1)."""
     cfg = model_cfg(model_name, **encoder_overrides)
+    if pred_rnn_layers is not None:
+        cfg["head"]["decoder"]["pred_rnn_layers"] = int(pred_rnn_layers)
     if isinstance(calib, str):
         calib = load_calib(cfg, seed)
     return {"cfg": copy.deepcopy(cfg), "state_dict": make_state_dict(cfg, seed, calib, rnnt_blank_bias)}

@@ -4,6 +4,7 @@ reference's own modules) and the tests (which regenerate the seeded weights/audi
 name -> (model, ckpt seed, n_layers, audio: (batch, seconds, seed, lengths), options)
 options: blank_bias  -- RNN-T: blank bias of the synthetic joint (synth.make_state_dict)
          max_symbols -- RNN-T: max_symbols_per_step of the decoding config (reference default 10)
+         pred_rnn_layers -- RNN-T: depth of the predictor's nn.LSTM (reference decoder.py:78-83; published checkpoints: 1)
 
 RNN-T cases come in two regimes:
   * blank-dominant (0.1-1 symbols per frame, what reference gigaam/decoding.py:162-205 sees on trained
@@ -25,6 +26,9 @@ CASES = {
     "v1_rnnt_l2": ("v1_rnnt", 1, 2, (2, 2.5, 20, [40000, 26000]), {"blank_bias": 14.0}),
     "v3_rnnt_l2": ("v3_rnnt", 1, 2, (2, 3.0, 21, [48000, 37000]), {"blank_bias": 15.0}),
     "v3_e2e_rnnt_l2": ("v3_e2e_rnnt", 1, 2, (2, 3.0, 35, [48000, 30011]), {"blank_bias": 14.0}),
+    # a TWO-layer predictor LSTM (reference decoder.py:78-83 builds nn.LSTM(.., pred_rnn_layers); every published checkpoint
+    # has 1): the one-workgroup decode kernel runs it (gam_decode.h), the cluster kernel is for L = 1
+    "v2_rnnt_l2_lstm2": ("v2_rnnt", 1, 2, (3, 4.0, 62, [64000, 45000, 52000]), {"blank_bias": 15.0, "pred_rnn_layers": 2}),
     # emission-heavy RNN-T (max_symbols cap reached on most frames)
     "v2_rnnt_l2_dense": ("v2_rnnt", 1, 2, (3, 4.0, 13, [64000, 41234, 57000]), {"blank_bias": 8.0}),
     "v3_e2e_rnnt_l2_dense": ("v3_e2e_rnnt", 1, 2, (2, 3.0, 45, [48000, 30011]), {"blank_bias": 7.0, "max_symbols": 3}),
@@ -39,7 +43,8 @@ def make_case_checkpoint(name_or_case):
     from gigaam_amd import synth
     case = CASES[name_or_case] if isinstance(name_or_case, str) else name_or_case
     model, seed, nl, (b, secs, aseed, lens), opt = case
-    ck = synth.make_checkpoint(model, seed=seed, n_layers=nl, rnnt_blank_bias=opt.get("blank_bias"))
+    ck = synth.make_checkpoint(model, seed=seed, n_layers=nl, rnnt_blank_bias=opt.get("blank_bias"),
+                               pred_rnn_layers=opt.get("pred_rnn_layers"))
     if "max_symbols" in opt:
         ck["cfg"]["decoding"]["max_symbols_per_step"] = opt["max_symbols"]
     wav, wlen = synth.synth_audio(b, secs, seed=aseed, lengths=lens)

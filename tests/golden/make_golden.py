@@ -111,7 +111,7 @@ def run_case(ref, case):
             dec = ref.decoding.RNNTGreedyDecoding(cfg["decoding"]["vocabulary"], max_symbols_per_step=ms)
             r = dec.decode(head, y_ref, l_ref)
             trace = []
-            o = O.rnnt_greedy(sd, y_ref, l_ref, ms, trace=trace)
+            o = O.rnnt_greedy(sd, y_ref, l_ref, ms, cfg["head"]["decoder"]["pred_rnn_layers"], trace=trace)
             stats["joint_steps"] = len(trace)
             marg = [float(t[2].topk(2).values[0] - t[2].topk(2).values[1]) for t in trace]
             stats["min_margin"] = min(marg)
@@ -144,11 +144,12 @@ def run_case(ref, case):
             stats["blank_step_frac"] = round(1.0 - n_tok / len(trace), 3)
             # pin predict/joint against the reference modules on the first steps
             g_ref, (h_ref, c_ref) = head.decoder.predict(None, None, batch_size=1)
-            g_or, (h_or, c_or) = O.rnnt_predict(sd, None, None)
+            nlp = cfg["head"]["decoder"]["pred_rnn_layers"]
+            g_or, (h_or, c_or) = O.rnnt_predict(sd, None, None, nlp)
             assert float((g_ref[0, 0] - g_or).abs().max()) < 1e-6
             lab = torch.tensor([[3]])
             g2_ref, (h2, c2) = head.decoder.predict(lab, (h_ref, c_ref), batch_size=1)
-            g2_or, (h2o, c2o) = O.rnnt_predict(sd, 3, (h_or, c_or))
+            g2_or, (h2o, c2o) = O.rnnt_predict(sd, 3, (h_or, c_or), nlp)
             assert float((g2_ref[0, 0] - g2_or).abs().max()) < 1e-6 and float((c2[:, 0] - c2o).abs().max()) < 1e-6
             f = y_ref.transpose(1, 2)[0:1, 5:6]
             j_ref = head.joint.joint(f, g2_ref)[0, 0, 0]

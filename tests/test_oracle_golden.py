@@ -32,7 +32,8 @@ def test_oracle_matches_reference_golden(case):
             got = O.ctc_greedy(lp, elen)
         else:
             trace = []
-            got = O.rnnt_greedy(sd, enc_ref, elen, cfg["decoding"]["max_symbols_per_step"], trace=trace)
+            got = O.rnnt_greedy(sd, enc_ref, elen, cfg["decoding"]["max_symbols_per_step"],
+                                cfg["head"]["decoder"]["pred_rnn_layers"], trace=trace)
             # every joint evaluation against the reference's own (RNNTJoint.joint recorded during its decode)
             for i, want in enumerate(golden_trace(gold)):
                 mine = torch.stack([t[2] for t in trace if t[0] == i])
