@@ -669,8 +669,8 @@ def main():
         else:
             # every algorithmic FLOP costs three fp16 MFMA FLOPs (hi.hi + hi.lo + lo.hi): the ceiling of
             # this arithmetic is a third of the fp16 dense peak
-            kern = ("gam_gemm_sp_kernel (LDS-DMA, sp32 operands; small GEMMs: gam_gemm_f16x3_kernel) -- 3x "
-                    "v_mfma_f32_32x32x16_f16 per product; plain + implicit-GEMM conv")
+            kern = ("gam_gemm_sp_kernel (LDS-DMA, sp32 operands, epilogue straight from the swapped-operand accumulators; split-K "
+                    "slices for small grids) -- 3x v_mfma_f32_32x32x16_f16 per product; plain + implicit-GEMM conv")
             peak, peak_note = F16_MFMA_PEAK_TFLOPS / 3.0, "fp16 dense MFMA peak (2500) / 3 issued MFMA FLOP per algorithmic FLOP"
         flop, ms, n, ach, frac = family(prof, peak)
         traffic, traffic_src = None, None

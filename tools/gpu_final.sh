@@ -1,8 +1,9 @@
 #!/bin/bash
 # Full measurement visit: GPU tests (with the measured-error report), smoke, the driver's bench command, a 1-rank
 # torchrun launch of the distributed path, rocprofv3 kernel trace + PMC passes (separate runs, as the guide
-# prescribes), and all five BASELINE configurations.  Everything lands under gpurun_out/$TAG/.
-#   gpurun --timeout 2400 -- 'bash tools/gpu_final.sh r02_final'
+# prescribes), all five BASELINE configurations, the strong-scaling proxies and the shared-device rehearsal of the
+# multi-rank program.  Everything lands under gpurun_out/$TAG/.
+#   gpurun --timeout 2400 -- 'bash tools/gpu_final.sh r03_final'
 TAG=${1:-final}
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD
@@ -22,17 +23,36 @@ B="python $R/bench.py --steps 1 --warmup 1 --cpu-utts 0 --no-profile --no-f32-le
 ( timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pf_write -o b -- $B ) > $OUT/pf_write.log 2>&1
 ( timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pf_sq -o b -- $B ) > $OUT/pf_sq.log 2>&1
 ( timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_trace_c3 -o b -- python $R/bench.py --config 3 --steps 3 --warmup 1 --cpu-utts 0 --no-f32-leg ) > $OUT/pf_trace_c3.log 2>&1
+( timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_trace_b4 -o b -- python $R/bench.py --batch 4 --steps 10 --warmup 3 --cpu-utts 0 --no-f32-leg --no-power --no-profile ) > $OUT/pf_trace_b4.log 2>&1
+( timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_trace_c1 -o b -- python $R/bench.py --config 1 --steps 10 --warmup 3 --cpu-utts 0 --no-profile ) > $OUT/pf_trace_c1.log 2>&1
 cd $R
-for n in trace fetch write sq trace_c3; do
+for n in trace fetch write sq trace_c3 trace_b4 trace_c1; do
   DB=$(find $OUT/pf_$n -name "*.db" | head -1)
-  [ -n "$DB" ] && python tools/rocpd_summary.py $DB $OUT/${n}_summary.txt "rocprofv3 pass '$n' of bench.py (config 2, f16x3; trace_c3: config 3)" > /dev/null 2>&1
+  [ -n "$DB" ] && python tools/rocpd_summary.py $DB $OUT/${n}_summary.txt "rocprofv3 pass '$n' of bench.py (config 2, f16x3; trace_c3: config 3; trace_b4: --batch 4; trace_c1: config 1)" > /dev/null 2>&1
 done
 FD=$(find $OUT/pf_fetch -name "*.db" | head -1); WD=$(find $OUT/pf_write -name "*.db" | head -1)
 [ -n "$FD" ] && [ -n "$WD" ] && python tools/pmc_traffic.py $FD $WD $OUT/pmc_traffic_f16x3.json > $OUT/pmc_traffic.log 2>&1
 find $OUT -name "*.db" -delete
 ( timeout 900 python tools/bench_configs.py --only 1,3,4,5 --out $OUT/configs.jsonl ) > $OUT/configs.log 2>&1; echo "configs rc=$?"
+# strong-scaling proxies: the per-rank workloads of the 1/2/4/8/16-GPU strong points of config 2 on ONE GPU
+C="--steps 30 --warmup 8 --no-f32-leg --no-power --cpu-utts 0"
+rm -f $OUT/strong_proxy.jsonl
+for b in 32 16 8 4 2; do
+  ( timeout 300 python bench.py --batch $b $C ) 2> $OUT/proxy_b$b.err | grep -a '^{' >> $OUT/strong_proxy.jsonl
+done
+# the multi-rank program on this 1-GPU box: plain --gpus 2 must refuse clearly; --oversubscribe runs it over gloo
+( python bench.py --gpus 2 --steps 3 --warmup 1 ) > $OUT/rehearsal_refused.out 2> $OUT/rehearsal_refused.err; echo "plain --gpus 2 rc=$? (expected 1)"
+for sc in weak strong; do
+  ( timeout 300 python bench.py --gpus 2 --oversubscribe --scaling $sc --steps 5 --warmup 2 --no-profile --cpu-utts 0 ) 2> $OUT/rehearsal_$sc.err | grep -a '^{' > $OUT/rehearsal_gpus2_$sc.json; echo "rehearsal $sc rc=$?"
+done
+( timeout 300 python bench.py --gpus 4 --oversubscribe --config 4 --utts-per-gpu 32 --steps 1 --warmup 1 --no-profile ) 2> $OUT/rehearsal_c4.err | grep -a '^{' > $OUT/rehearsal_gpus4_config4.json; echo "rehearsal config4 x4 rc=$?"
 tail -3 $OUT/pytest_gpu.log; tail -1 $OUT/smoke.log
 grep -a "^{" $OUT/bench.log | cut -c1-400
 grep -a "^{" $OUT/bench_torchrun1.log | cut -c1-200
 cat $OUT/configs.log | cut -c1-300
-head -12 $OUT/trace_summary.txt | cut -c1-150
+python - <<PY
+import json
+for l in open("$OUT/strong_proxy.jsonl"):
+    d = json.loads(l); print("proxy batch", d["config"]["global_batch"], d["ms_per_step"], "ms", d["value"], d.get("kernel_classes_ms_per_step"))
+PY
+head -14 $OUT/trace_summary.txt | cut -c1-150
