@@ -532,20 +532,18 @@ def main():
         feeder = BatchFeeder(my_segs, fr_bs, dev) if my_segs else []       # pinned staging buffers: allocated once
         last5 = {}
         if rank == 0:
-            # CPU-oracle leg: the longest chunk (the T' <= 751 case no other configuration reaches) + three spread over the file
+            # CPU-oracle leg: four rows of the batch that holds the file's longest chunk, cut from that batch's OWN zero-padded
+            # tensor -- the reference's features of an utterance's last frames depend on what follows it in its row (zero
+            # padding inside a batch, reflect padding at the end of the longest row: torchaudio center=True pads the TENSOR),
+            # so the oracle must see each chunk exactly as the GPU's batch held it, not re-collated with other neighbours
             from gigaam_amd.feeder import collate
             order = sorted(range(len(segs)), key=lambda i: -int(segs[i].shape[0]))
-            pick = [order[0]] + [i for i in (0, len(segs) // 2, len(segs) - 1) if i != order[0]][:3]
-            # Over 194 chunks x ~550 frames a random-init head has frames whose top-2 margin is below any fp32 implementation's
-            # reproducibility; the full-size golden generator (tests/golden/make_longform_golden.py) examined the longest chunks
-            # with the REFERENCE's modules and recorded the ones whose margin exceeds 1e-3 -- those are decoded here.
-            mp = os.path.join(ROOT, "tests", "golden", "fullsize_meta.json")
-            if os.path.exists(mp):
-                m5 = json.load(open(mp)).get("fullsize_v2_ctc_longform", {})
-                if m5.get("n_chunks") == len(segs) and m5.get("cpu_leg_chunks") and order[0] in m5["cpu_leg_chunks"]:
-                    pick = [order[0]] + [i for i in m5["cpu_leg_chunks"] if i != order[0]][:3]
-            w5, l5 = collate([segs[i] for i in pick])
-            cpu_sample = (w5, l5, pick)
+            jb = order[0] // fr_bs
+            rows5 = list(range(jb * fr_bs, min(len(segs), (jb + 1) * fr_bs)))
+            w5, l5 = collate([segs[i] for i in rows5])
+            r0 = order[0] - jb * fr_bs
+            sel = [r0] + [r for r in sorted(range(len(rows5)), key=lambda r: -int(l5[r])) if r != r0][:3]
+            cpu_sample = (w5[sel].contiguous(), l5[sel].contiguous(), [rows5[r] for r in sel])
 
         trace = os.environ.get("GAM_BENCH_TRACE")   # debug: host timestamps per batch (ms since the step began)
 

@@ -8,7 +8,7 @@ regions are short), the longest chunk of the very chunk list bench.py --config 5
 long chunks whose CTC argmax margin is widest (near-ties of a random-init head are below any fp32 implementation's
 reproducibility; the margins of the kept chunks are recorded).  The three are decoded as ONE zero-padded batch, as
 transcribe_longform would (reference gigaam/model.py:219-236, AudioDataset.collate), so the key-padding masks of the
-shorter ones are exercised too.  ``cpu_leg_chunks`` lists the chunks (margin >= 1e-3) bench.py's CPU-oracle leg decodes.
+shorter ones are exercised too.  (``cpu_leg_chunks`` in the meta file: the examined chunks by margin, for the record.)
 
     python tests/golden/make_longform_golden.py      ->  fullsize_v2_ctc_longform.npz, fullsize_meta.json
 """
@@ -103,7 +103,7 @@ def main():
     out = dict(enc_len=l_ref.numpy(), enc_probe=y_ref[:, ::16, ::5].numpy(), wav_len=wlen.numpy(), utt_index=np.asarray([-1] + idx[1:], np.int32),
                ids=np.asarray(ids_flat, np.int32), frames=np.asarray(frames_flat, np.int32), counts=np.asarray(counts, np.int32))
     np.savez_compressed(os.path.join(HERE, NAME + ".npz"), **out)
-    cpu_leg = sorted(pair_margins, key=lambda i: -pair_margins[i])[:4]       # bench.py --config 5's CPU-oracle leg decodes these
+    cpu_leg = sorted(pair_margins, key=lambda i: -pair_margins[i])[:4]       # (the examined chunks, widest margin first)
     if longest not in cpu_leg:
         cpu_leg = [longest] + cpu_leg[:3]
     st = dict(model="v2_ctc", n_utts=len(idx), chunk_index=[-1] + idx[1:], strict_window_offset_s=sbest[1], strict_window_s=STRICT_S,
