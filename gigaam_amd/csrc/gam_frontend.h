@@ -52,16 +52,35 @@ __global__ __launch_bounds__(256) void gam_powmel_kernel(GamPowMelArgs a) {
     if ((num % a.hop != 0) && (num < 0)) qd -= 1;
     a.feat_len[b] = qd + 1;
   }
-  for (int idx = tid; idx < 64 * a.nf; idx += 256) {
-    const int fl = idx / a.nf, f = idx - fl * a.nf;
-    const int t = t0 + fl;
-    float p = 0.f;
-    if (t < a.Tf) {
-      const float* sp = a.spec + ((size_t)b * a.Tfa + t) * a.lds;
-      const float re = sp[f], im = sp[a.nf + f];
-      p = re * re + im * im;
+  // power spectrum of the block's 64 frames: wave w takes frames w, w + 4, ..; a frame's bins are read lane-contiguous
+  // (no per-element index division; all loads of a frame in flight before the first use)
+  {
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int fl = wv; fl < 64; fl += 4) {
+      const int t = t0 + fl;
+      float* pr = gam_smem_pm + fl * pld;
+      if (t < a.Tf) {
+        const float* sp = a.spec + ((size_t)b * a.Tfa + t) * a.lds;
+        float re[4], im[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int f = lane + 64 * u, fc = f < a.nf ? f : a.nf - 1;
+          re[u] = sp[fc];
+          im[u] = sp[a.nf + fc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int f = lane + 64 * u;
+          if (f < a.nf) pr[f] = re[u] * re[u] + im[u] * im[u];
+        }
+        for (int f = lane + 256; f < a.nf; f += 64) {   // (n_fft > 510: not a published configuration)
+          const float r2 = sp[f], i2 = sp[a.nf + f];
+          pr[f] = r2 * r2 + i2 * i2;
+        }
+      } else {
+        for (int f = lane; f < a.nf; f += 64) pr[f] = 0.f;
+      }
     }
-    gam_smem_pm[fl * pld + f] = p;
   }
   __syncthreads();
   // mel projection: the filterbank is triangular (a bin feeds <= 2 bands), so each band sums only its

@@ -768,3 +768,24 @@ def test_transcribe_result_structure_v3(revision, tmp_path):
         assert seg.words is not None and all(isinstance(w, Word) for w in seg.words)
         assert all(seg.start - 1e-6 <= w.start < w.end <= seg.end + 0.05 for w in seg.words)
     assert len(lfw.words) > 0 and all(w.start < w.end for w in lfw.words)
+
+
+@pytest.mark.parametrize("case", ["v2_ctc_l2", "v3_ctc_l2", "v1_ctc_l2"])
+def test_fused_splitk_reduce_is_bit_identical(case, monkeypatch):
+    """r03: at small grids the residual GEMMs run as split-K slices whose sum is taken by the LayerNorm that follows
+    (gam_norm.h) instead of gam_splitk_reduce_kernel.  Both add the slices in slice order and apply bias, alpha and the
+    residual in the same order, so the encoder output must be BIT-identical with the fusion on and off -- and identical
+    from run to run (no atomics anywhere in the reduction)."""
+    from gigaam_amd.engine import HipEngine, build_config
+    ck, wav, wlen, gold = load_case(case)
+    cfg = ck["cfg"]
+    feat_o, flen_o = oracle_features(ck, wav, wlen)
+    outs = []
+    for fuse in ("1", "0", "1"):
+        monkeypatch.setenv("GAM_FUSE_REDUCE", fuse)
+        eng = HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], cfg["head"]), ck["state_dict"], torch.device("cuda:0"))
+        enc, elen = eng.encode(feat_o, flen_o)
+        outs.append(enc.cpu())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    vm = valid_mask(outs[0].shape[2], gold["enc_len"])
+    assert float(((outs[0] - torch.from_numpy(gold["encoded"])) * vm[:, None, :]).abs().max()) < TOL_ENC
