@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of an environment switch on the headline step (same box, interleaved):  bash tools/r03_ab.sh TAG VAR v1 v2 ... [-- extra bench args]
+# A/B of an environment switch on the headline step (same box, interleaved):  bash tools/ab_env.sh TAG VAR v1 v2 ... [-- extra bench args]
 TAG=$1; VAR=$2; shift 2
 VALS=(); while [[ $# -gt 0 && $1 != "--" ]]; do VALS+=("$1"); shift; done; [[ $1 == "--" ]] && shift
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
