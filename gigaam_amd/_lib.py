@@ -58,6 +58,7 @@ SIGNATURES = {
     "gam_op_gemm": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "gam_op_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "gam_tune_sp": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "gam_plan_sp": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gam_profile_enable": (C.c_int, [_P, C.c_int]),
     "gam_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "gam_profile_read_bytes": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),

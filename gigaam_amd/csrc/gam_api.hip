@@ -1430,6 +1430,13 @@ int gam_range_flag_fetch(gam_handle* h, int32_t* flag_dev, void* stream) {
   return 0;
 }
 
+int gam_plan_sp(int M, int N, int K, int n_cu, int* mt, int* nw, int* splitk) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0 || !mt || !nw || !splitk) return -1;
+  const GamSpPlan p = gam_gemm_sp_plan(M, N, K, 0, n_cu > 0 ? n_cu : 256);
+  *mt = p.mt; *nw = p.nw; *splitk = p.s;
+  return 0;
+}
+
 int gam_tune_sp(int mt, int nw, int splitk) {
   g_gam_sp_force[0] = mt; g_gam_sp_force[1] = nw; g_gam_sp_force[2] = splitk;
   return 0;

@@ -154,6 +154,9 @@ int gam_op_attention(gam_handle* h, const float* q, const float* k, const float*
 /* Tuning hook of the large-M GEMM (tools/smallm_sweep.py): force the tile shape (mt in 2..4 rows of 64, nw in {2, 4}
  * columns of 64) and / or the split-K factor of every following launch in this process; 0 = planned per launch (default). */
 int gam_tune_sp(int mt, int nw, int splitk);
+/* The plan a launch of C[M,N] = A[M,K].W[N,K]^T would get on a device with n_cu compute units (host-side only: no GPU
+ * needed; K % 32 == 0): tile rows = 64 * mt, tile columns = 64 * nw, split-K slices. */
+int gam_plan_sp(int M, int N, int K, int n_cu, int* mt, int* nw, int* splitk);
 
 /* Per-kernel-class HIP-event timing on the launch stream (bench.py's roofline leg).
  * gam_profile_enable(h,1) starts collecting for every launch, (h,2) for the GEMM family only

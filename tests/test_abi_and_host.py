@@ -255,3 +255,35 @@ def test_rnnt_head_exposes_decoder_and_joint_views():
         with pytest.raises(NotImplementedError, match="gam_rnnt_greedy"):
             call()
     assert "decoder" not in dict(h.named_children())       # views, not sub-modules: nothing to move or serialise
+
+
+def test_gemm_plan_invariants():
+    """gam_gemm_sp_plan is host code (no GPU): tile shape x split-K per launch from the time model fitted to
+    profiles/r03_smallm_sweep.txt.  Pinned here: the invariants the kernel relies on (whole k-tiles per slice, at least four
+    of them, split-K only for grids under half the chip) and the choices the sweep found best at the sizes that matter."""
+    import ctypes as C
+    from gigaam_amd import _lib
+    lib = _lib.load_library()
+    lib.gam_tune_sp(0, 0, 0)
+
+    def plan(m, n, k, ncu=256):
+        mt, nw, s = C.c_int(), C.c_int(), C.c_int()
+        assert lib.gam_plan_sp(m, n, k, ncu, C.byref(mt), C.byref(nw), C.byref(s)) == 0
+        return mt.value, nw.value, s.value
+
+    for m in (5, 126, 501, 1004, 2008, 4016, 8032, 16064, 40000):
+        for n, k in ((768, 768), (1536, 768), (3072, 768), (768, 3072), (768, 12288), (320, 768), (768, 6912)):
+            mt, nw, s = plan(m, n, k)
+            assert mt in (2, 3, 4) and nw in (2, 4) and not (nw == 2 and mt == 4) and 1 <= s <= 8
+            nk = k // 32
+            tiles = -(-m // (64 * mt)) * -(-n // (64 * nw))
+            if s > 1:
+                assert nk % s == 0 and nk // s >= 4 and tiles * 2 <= 256, (m, n, k, mt, nw, s)
+    # the headline batch: full-width tiles, no split-K (sweep: 3x4 / 4x4 / 3x4 best)
+    assert plan(16064, 768, 768) == (3, 4, 1) and plan(16064, 3072, 768) == (4, 4, 1) and plan(16064, 768, 3072) == (3, 4, 1)
+    # a single clip and the 8-GPU strong point: split-K slices fill the chip
+    assert plan(126, 768, 768)[2] >= 4 and plan(126, 768, 3072)[2] == 8 and plan(2008, 768, 3072)[2] >= 3
+    assert plan(2008, 3072, 768)[2] == 1          # 384 tiles already: no slices
+    # a partition with fewer CUs shifts the trade
+    assert plan(4016, 768, 768, ncu=64)[2] == 1
+    assert lib.gam_plan_sp(100, 100, 100, 256, C.byref(C.c_int()), C.byref(C.c_int()), C.byref(C.c_int())) != 0   # K % 32
