@@ -17,12 +17,16 @@
 #define GAM_A16_VLD 72   // halfs per V^T-plane row (144 B = 9 x 16 B)
 
 __device__ __forceinline__ void gam_split8(const float (&v)[8], gam_half8& hi, gam_half8& lo) {
+  gam_u32x4 h, l;   // (gam_common.h gam_split2: 4 VALU instructions per pair)
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const _Float16 h = (_Float16)v[i];
-    hi[i] = h;
-    lo[i] = (_Float16)(v[i] - (float)h);
+  for (int i = 0; i < 4; ++i) {
+    unsigned hh, ll;
+    gam_split2(v[2 * i], v[2 * i + 1], hh, ll);
+    h[i] = hh;
+    l[i] = ll;
   }
+  hi = __builtin_bit_cast(gam_half8, h);
+  lo = __builtin_bit_cast(gam_half8, l);
 }
 
 // REL: the relative-position scores of v1 models (gam_attn.h, reference encoder.py:191-228):

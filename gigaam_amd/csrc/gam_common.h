@@ -50,12 +50,30 @@ typedef _Float16 gam_half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 gam_half8 __attribute__((ext_vector_type(8)));
 typedef unsigned gam_u32x4 __attribute__((ext_vector_type(4)));
 
-// x = hi + lo, hi = fp16(x), lo = fp16(x - hi): the split-fp16 operand format (gam_gemm16.h)
+// x = hi + lo, hi = fp16(x), lo = fp16(x - hi): the split-fp16 operand format (gam_gemm16.h).
+// Two elements cost 4 VALU instructions: one packed convert for the hi pair, one v_fma_mix_f32 per element for x - hi (the
+// mixed-precision FMA reads the fp16 half in place: no convert back), one packed convert for the lo pair.  hipcc's own code for
+// the C expression is 13 instructions per 4 elements (it converts every hi back to fp32 first); the split sits in VALU-bound
+// places -- the attention kernel's K / V / P operands, the SiLU epilogue of the FFN-up GEMM.  Same roundings, same bits.
+// The two converts are left to the compiler on purpose: hipcc's hazard recognizer does not look inside inline asm, and a
+// first version with all four instructions in asm read its inputs too early behind v_exp_f32 (attention's P = 2^x: NaNs).
+// Here the compiler-issued convert of the SAME inputs always precedes the two asm instructions, so every producer -> VALU
+// wait state has passed by the time they issue; their other input is the convert's own (plain VALU) result.
+typedef unsigned gam_u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 gam_half2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gam_split2(float a, float b, unsigned& hi, unsigned& lo) {   // hi / lo: packed fp16 pairs
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){a, b}, gam_half2));      // v_cvt_pk_f16_f32
+  float la, lb;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(la) : "v"(hi), "v"(a));   // a - (float)hi.lo16
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hi), "v"(b));   // b - (float)hi.hi16
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2){la, lb}, gam_half2));
+}
 __device__ __forceinline__ void gam_split4(const f32x4 v, gam_half4& hi, gam_half4& lo) {
-  const _Float16 h0 = (_Float16)v.x, h1 = (_Float16)v.y, h2 = (_Float16)v.z, h3 = (_Float16)v.w;
-  hi = (gam_half4){h0, h1, h2, h3};
-  lo = (gam_half4){(_Float16)(v.x - (float)h0), (_Float16)(v.y - (float)h1), (_Float16)(v.z - (float)h2),
-                   (_Float16)(v.w - (float)h3)};
+  unsigned h0, h1, l0, l1;
+  gam_split2(v.x, v.y, h0, l0);
+  gam_split2(v.z, v.w, h1, l1);
+  hi = __builtin_bit_cast(gam_half4, (gam_u32x2){h0, h1});
+  lo = __builtin_bit_cast(gam_half4, (gam_u32x2){l0, l1});
 }
 
 // Per-row power-of-two pre-scale of a split-fp16 A operand (the activations' counterpart of the weights' 2^s,
@@ -99,11 +117,11 @@ __device__ __forceinline__ void gam_store2(float* base, size_t row_off, int c, f
   if (!split) {
     *reinterpret_cast<float2*>(base + row_off + c) = make_float2(x0, x1);
   } else {
-    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
     _Float16* p = reinterpret_cast<_Float16*>(base) + row_off * 2 + (c >> 5) * 64 + (c & 31);
-    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
-    *reinterpret_cast<half2_t*>(p) = (half2_t){h0, h1};
-    *reinterpret_cast<half2_t*>(p + 32) = (half2_t){(_Float16)(x0 - (float)h0), (_Float16)(x1 - (float)h1)};
+    unsigned h, l;
+    gam_split2(x0, x1, h, l);
+    *reinterpret_cast<unsigned*>(p) = h;
+    *reinterpret_cast<unsigned*>(p + 32) = l;
   }
 }
 __device__ __forceinline__ void gam_store1(float* base, size_t row_off, int c, float x, int split) {
