@@ -334,7 +334,7 @@ static inline hipError_t gam_launch_gemm(const GamGemmArgs& a_in, int act, hipSt
 
 // ---- split-K second pass: C = epilogue(sum_s partial[s]) with the same epilogue semantics as above.
 //      One thread per 4 consecutive columns (N % 4 == 0) or per column.
-template <int ACT, int VEC>
+template <int ACT, int VEC, int SMAX = 16>   // SMAX: largest S with all slices in flight (4: the lean instantiation for S <= 4)
 __global__ __launch_bounds__(256) void gam_splitk_reduce_kernel(GamGemmArgs g, int S) {
   const int cpr = (g.N + VEC - 1) / VEC;                       // column groups per row
   const size_t total = (size_t)g.M * cpr;
@@ -345,13 +345,11 @@ __global__ __launch_bounds__(256) void gam_splitk_reduce_kernel(GamGemmArgs g, i
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v[e] = 0.f;
     const float* p = g.partial + (size_t)row * g.N + col;
-    for (int s = 0; s < S; ++s) {
-      if (VEC == 4) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(p + s * slice);
-        v[0] += t.x; v[1 % VEC] += t.y; v[2 % VEC] += t.z; v[3 % VEC] += t.w;
-      } else {
-        v[0] += p[s * slice];
-      }
+    if (VEC == 4) {   // all S slices in flight, summed in slice order (gam_common.h)
+      const f32x4 t = gam_sum_slices<SMAX>(p, slice, S);
+      v[0] = t.x; v[1 % VEC] = t.y; v[2 % VEC] = t.z; v[3 % VEC] = t.w;
+    } else {
+      for (int s = 0; s < S; ++s) v[0] += p[s * slice];
     }
     bool masked = false;
     long orow = row;
@@ -392,7 +390,8 @@ static inline hipError_t gam_launch_splitk_reduce(const GamGemmArgs& a, int act,
   const size_t total = (size_t)a.M * (vec ? a.N / 4 : a.N);
   const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
 #define GAM_RED(ACTV)                                                                                      \
-  if (vec) hipLaunchKernelGGL((gam_splitk_reduce_kernel<ACTV, 4>), dim3(grid), dim3(256), 0, stream, a, S); \
+  if (vec && S <= 4) hipLaunchKernelGGL((gam_splitk_reduce_kernel<ACTV, 4, 4>), dim3(grid), dim3(256), 0, stream, a, S); \
+  else if (vec) hipLaunchKernelGGL((gam_splitk_reduce_kernel<ACTV, 4, 16>), dim3(grid), dim3(256), 0, stream, a, S); \
   else hipLaunchKernelGGL((gam_splitk_reduce_kernel<ACTV, 1>), dim3(grid), dim3(256), 0, stream, a, S);
   switch (act) {
     case GAM_ACT_SILU: GAM_RED(GAM_ACT_SILU); break;

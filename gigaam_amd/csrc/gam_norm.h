@@ -77,7 +77,9 @@ __device__ __forceinline__ void gam_ln_row(float4 (&v)[GAM_LN_MAXJ], int d, int 
   }
 }
 
-template <int MODE>
+// PART: the fused split-K reduce (a.part != nullptr) -- its own instantiation, so that the plain kernel keeps its 24 VGPRs
+// (the unrolled slice loads of the fused one take ~100).
+template <int MODE, bool PART = false>
 __global__ __launch_bounds__(256) void gam_layernorm_kernel(GamLnArgs a) {
   __shared__ float rowbuf[MODE == 1 ? 4 * GAM_LN_MAXJ * 256 : 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -86,18 +88,15 @@ __global__ __launch_bounds__(256) void gam_layernorm_kernel(GamLnArgs a) {
   const int row = live ? row_raw : a.rows - 1;
   const float* xr = a.x + (size_t)row * a.d;
   float4 v[GAM_LN_MAXJ];
-  if (a.part != nullptr) {   // fused split-K reduce: the row is finished here (see GamLnArgs)
+  if constexpr (PART) {   // fused split-K reduce: the row is finished here (see GamLnArgs)
     const size_t slice = (size_t)a.rows * a.d;
 #pragma unroll
     for (int j = 0; j < GAM_LN_MAXJ; ++j) {
       const int c = (j * 64 + lane) * 4;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c < a.d) {
-        const float* pr = a.part + (size_t)row * a.d + c;
-        for (int sl = 0; sl < a.nsplit; ++sl) {
-          const float4 t = *reinterpret_cast<const float4*>(pr + sl * slice);
-          acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-        }
+        const f32x4 sm = gam_sum_slices<8>(a.part + (size_t)row * a.d + c, slice, a.nsplit);
+        acc = make_float4(sm.x, sm.y, sm.z, sm.w);
         if (a.pbias != nullptr) {
           const float4 bb = *reinterpret_cast<const float4*>(a.pbias + c);
           acc.x += bb.x; acc.y += bb.y; acc.z += bb.z; acc.w += bb.w;
@@ -196,8 +195,12 @@ static inline hipError_t gam_launch_layernorm(const GamLnArgs& a, int mode, hipS
   if ((a.split1 || a.split2) && a.d % 32 != 0) return hipErrorInvalidValue;
   if (mode == 1 && (a.dk % 8 != 0 || a.d % a.dk != 0)) return hipErrorInvalidValue;   // rope: 4-element groups stay inside a half head
   const int grid = gam_cdiv(a.rows, 4);
-  if (mode == 0) hipLaunchKernelGGL(gam_layernorm_kernel<0>, dim3(grid), dim3(256), 0, s, a);
-  else if (mode == 1) hipLaunchKernelGGL(gam_layernorm_kernel<1>, dim3(grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(gam_layernorm_kernel<2>, dim3(grid), dim3(256), 0, s, a);
+  if (a.part != nullptr) {
+    if (mode == 0) hipLaunchKernelGGL((gam_layernorm_kernel<0, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((gam_layernorm_kernel<1, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gam_layernorm_kernel<2, true>), dim3(grid), dim3(256), 0, s, a);
+  } else if (mode == 0) hipLaunchKernelGGL((gam_layernorm_kernel<0, false>), dim3(grid), dim3(256), 0, s, a);
+  else if (mode == 1) hipLaunchKernelGGL((gam_layernorm_kernel<1, false>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gam_layernorm_kernel<2, false>), dim3(grid), dim3(256), 0, s, a);
   return hipGetLastError();
 }
