@@ -571,15 +571,25 @@ def main():
                     "double-buffered feeder, CTC greedy, gather, detokenise")
 
     # ---- timing: W warm-up steps, then EXACTLY K steps between barrier + synchronize pairs; max over ranks
+    # Per-launch HIP-event pairs around the GEMM family INSIDE the timed region (the roofline's launch durations), on every
+    # PROF_EVERY-th timed step: an event pair costs ~3 us on this runtime (it drains the queue between kernels), 0.9 ms of a
+    # fully instrumented 33 ms step and 1 ms of an 8 ms one -- sampling keeps the measurement from moving what it measures.
+    PROF_EVERY = 4
+    n_prof_steps = (args.steps + PROF_EVERY - 1) // PROF_EVERY
+
     def timed(k_steps, profile):
         barrier_sync()
         if profile:
-            eng.profile_enable(2)      # inside the timed region: events around the GEMM family only
+            eng.profile_enable(0)      # reset the collectors
         t0 = time.perf_counter()
         out_ = None
-        for _ in range(k_steps):
+        for i in range(k_steps):
+            if profile:
+                eng.profile_level(2 if i % PROF_EVERY == 0 else 0)
             out_ = step()
         barrier_sync()
+        if profile:
+            eng.profile_level(0)
         return max_over_ranks(time.perf_counter() - t0), out_
 
     for _ in range(args.warmup):
@@ -682,9 +692,10 @@ def main():
             "frac": round(frac, 4), "traffic": traffic, "traffic_source": traffic_src,
             "peak_note": peak_note, "issued_mfma_tflops": round(ach * (1.0 if args.gemm == "f32" else 3.0), 1),
             "algorithmic_bytes_per_launch": round(alg_bytes / max(1, n)),
-            "launches_per_step": n // max(1, args.steps), "avg_launch_ms": round(ms / max(1, n), 4),
-            "algorithmic_gflop_per_step": round(flop / args.steps / 1e9, 1),
-            "share_of_step_time": round(ms / args.steps / ms_step, 3),
+            "launches_per_step": n // max(1, n_prof_steps), "avg_launch_ms": round(ms / max(1, n), 4),
+            "algorithmic_gflop_per_step": round(flop / n_prof_steps / 1e9, 1),
+            "share_of_step_time": round(ms / n_prof_steps / ms_step, 3),
+            "events": f"per-launch HIP event pairs on every {PROF_EVERY}th timed step ({n_prof_steps} of {args.steps})",
         }
         line["kernel_classes_ms_per_step"] = {k: round(v["ms"], 3) for k, v in prof_all.items() if v["launches"]}
         line["kernel_classes_note"] = "HIP-event time per class from one extra untimed step"
@@ -719,7 +730,7 @@ def main():
                "ids_identical_to_default_mode": sum(a == b for a, b in zip(out32, out)), "utterances": len(out)}
         if p32 is not None:
             flop, ms, n, ach, frac = family(p32, FP32_MFMA_PEAK_TFLOPS)
-            leg.update(achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, frac=round(frac, 4), launches_per_step=n // max(1, args.steps),
+            leg.update(achieved=round(ach, 2), peak=FP32_MFMA_PEAK_TFLOPS, frac=round(frac, 4), launches_per_step=n // max(1, n_prof_steps),
                        avg_launch_ms=round(ms / max(1, n), 4))
         line["roofline_f32_exact"] = leg
     n_cpu = args.cpu_utts if args.cpu_utts >= 0 else (32 if cfgno == 2 else 4)

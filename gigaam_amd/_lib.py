@@ -60,6 +60,7 @@ SIGNATURES = {
     "gam_tune_sp": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "gam_plan_sp": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gam_profile_enable": (C.c_int, [_P, C.c_int]),
+    "gam_profile_pause": (C.c_int, [_P, C.c_int]),
     "gam_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "gam_profile_read_bytes": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double)]),
     "gam_last_error": (C.c_char_p, [_P]),

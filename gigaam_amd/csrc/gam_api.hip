@@ -1450,6 +1450,12 @@ int gam_profile_enable(gam_handle* h, int on) {
   return 0;
 }
 
+int gam_profile_pause(gam_handle* h, int on) {
+  if (!h) return -1;
+  h->prof_on = on;      // (no reset: what was collected so far stays)
+  return 0;
+}
+
 int gam_profile_read_bytes(gam_handle* h, int cls, double* bytes) {
   if (!h || cls < 0 || cls >= GAM_PF_NCLASS || !bytes) return -1;
   *bytes = h->prof_bytes[cls];

@@ -296,6 +296,10 @@ class HipEngine:
         """True/1: time every launch; 2: GEMM family only; False/0: off."""
         self._check(self.lib.gam_profile_enable(self._h, int(on)), "gam_profile_enable")
 
+    def profile_level(self, on) -> None:
+        """Change the collection level without resetting (sampled profiling: gam_profile_pause)."""
+        self._check(self.lib.gam_profile_pause(self._h, int(on)), "gam_profile_pause")
+
     def profile_read(self) -> Dict[str, Dict[str, float]]:
         out = {}
         for i, name in enumerate(_lib.PF_CLASSES):

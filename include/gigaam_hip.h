@@ -167,6 +167,9 @@ enum { GAM_PF_GEMM = 0, GAM_PF_CONV2 = 1, GAM_PF_ATTN = 2, GAM_PF_NORM = 3, GAM_
        GAM_PF_STEM = 5, GAM_PF_FRONTEND = 6, GAM_PF_DECODE = 7, GAM_PF_MISC = 8, GAM_PF_NCLASS = 9 };
 int gam_profile_enable(gam_handle* h, int on);
 int gam_profile_read(gam_handle* h, int cls, double* ms, int64_t* launches, double* work);
+/* Switch the collection level (0 / 1 / 2) WITHOUT resetting what was collected: bench.py samples every 4th timed step (an
+ * event pair costs ~3 us on this runtime: 0.9 ms of a fully instrumented 33 ms step). */
+int gam_profile_pause(gam_handle* h, int on);
 /* algorithmic (unique operand + result) bytes of the timed launches of a GEMM class */
 int gam_profile_read_bytes(gam_handle* h, int cls, double* bytes);
 

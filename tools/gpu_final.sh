@@ -35,11 +35,7 @@ FD=$(find $OUT/pf_fetch -name "*.db" | head -1); WD=$(find $OUT/pf_write -name "
 find $OUT -name "*.db" -delete
 ( timeout 900 python tools/bench_configs.py --only 1,3,4,5 --out $OUT/configs.jsonl ) > $OUT/configs.log 2>&1; echo "configs rc=$?"
 # strong-scaling proxies: the per-rank workloads of the 1/2/4/8/16-GPU strong points of config 2 on ONE GPU
-C="--steps 30 --warmup 8 --no-f32-leg --no-power --cpu-utts 0"
-rm -f $OUT/strong_proxy.jsonl
-for b in 32 16 8 4 2; do
-  ( timeout 300 python bench.py --batch $b $C ) 2> $OUT/proxy_b$b.err | grep -a '^{' >> $OUT/strong_proxy.jsonl
-done
+bash tools/strong_proxy.sh $TAG > $OUT/strong_proxy.log 2>&1; cat $OUT/strong_proxy.log
 # the multi-rank program on this 1-GPU box: plain --gpus 2 must refuse clearly; --oversubscribe runs it over gloo
 ( python bench.py --gpus 2 --steps 3 --warmup 1 ) > $OUT/rehearsal_refused.out 2> $OUT/rehearsal_refused.err; echo "plain --gpus 2 rc=$? (expected 1)"
 for sc in weak strong; do
@@ -50,9 +46,4 @@ tail -3 $OUT/pytest_gpu.log; tail -1 $OUT/smoke.log
 grep -a "^{" $OUT/bench.log | cut -c1-400
 grep -a "^{" $OUT/bench_torchrun1.log | cut -c1-200
 cat $OUT/configs.log | cut -c1-300
-python - <<PY
-import json
-for l in open("$OUT/strong_proxy.jsonl"):
-    d = json.loads(l); print("proxy batch", d["config"]["global_batch"], d["ms_per_step"], "ms", d["value"], d.get("kernel_classes_ms_per_step"))
-PY
 head -14 $OUT/trace_summary.txt | cut -c1-150
