@@ -36,21 +36,48 @@ __global__ __launch_bounds__(256) void gam_ctc_greedy_kernel(const float* logits
   const int blank = V - 1;
   int len = enc_len[b];
   len = len < 0 ? 0 : (len > Tp ? Tp : len);   // decoding.py:76 clamp
-  for (int t = wave; t < Tp; t += 4) {
-    const float* xr = logits + ((size_t)b * Tp + t) * V;
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int v = lane; v < V; v += 64) {
-      const float x = xr[v];
-      if (x > best || (x == best && v < bi)) { best = x; bi = v; }
-    }
+  if (V <= 64) {
+    // character vocabularies (V = 34): a frame's logits are ONE load per lane, and the loop is a chain of dependent L2 round
+    // trips (32 utterances = 32 workgroups: nothing else hides them) -- eight frames per wave are in flight at once
+    // (108 -> ~25 us for 501 frames)
+    constexpr int FRU = 8;
+    for (int t0 = wave * FRU; t0 < Tp; t0 += 4 * FRU) {
+      float x[FRU];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ob = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      for (int u = 0; u < FRU; ++u) {
+        const int tt = t0 + u < Tp ? t0 + u : Tp - 1;
+        x[u] = logits[((size_t)b * Tp + tt) * V + (lane < V ? lane : V - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < FRU; ++u) {
+        float best = lane < V ? x[u] : -INFINITY;
+        int bi = lane < V ? lane : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ob = __shfl_xor(best, o, 64);
+          const int oi = __shfl_xor(bi, o, 64);
+          if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0 && t0 + u < Tp) lab[t0 + u] = bi;
+      }
     }
-    if (lane == 0) lab[t] = bi;
+  } else {
+    for (int t = wave; t < Tp; t += 4) {
+      const float* xr = logits + ((size_t)b * Tp + t) * V;
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
+      for (int v = lane; v < V; v += 64) {
+        const float x = xr[v];
+        if (x > best || (x == best && v < bi)) { best = x; bi = v; }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      }
+      if (lane == 0) lab[t] = bi;
+    }
   }
   __syncthreads();
   int base = 0;
