@@ -79,8 +79,10 @@ struct gam_handle {
   std::string err;
 
   // frontend
-  float *dft_basis = nullptr, *mel_fb = nullptr;
-  int* mel_band = nullptr;   // [2 * n_mels] non-zero bin range of each mel band
+  float* dft_basis = nullptr;
+  int* mel_band = nullptr;   // [3 * n_mels] per mel band: first / one-past-last bin with a non-zero weight, offset into mel_wts
+  float* mel_wts = nullptr;  // the non-zero stretch of every band's filter, band after band (gam_powmel_kernel keeps it in LDS)
+  int mel_nw = 0;            // floats in mel_wts
   int nf = 0, kpad = 0;
   // stem
   float *c1_w = nullptr, *c1_b = nullptr, *c2_w = nullptr, *c2_b = nullptr, *lin_w = nullptr, *lin_b = nullptr;
@@ -335,7 +337,7 @@ int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls
     e = gam_launch_gemm_sp(a, act, s);
     if (e != hipSuccess) return fail(h, -2, "sp gemm launch (M=%d N=%d K=%d): %s", a.M, a.N, a.K, hipGetErrorString(e));
     if (plan.s > 1 && defer != nullptr && h->fuse_reduce && act == GAM_ACT_NONE && !a.c_split && !a.c_guard && a.lens == nullptr &&
-        !a.remap && a.ldc == a.N && (a.R == nullptr || a.ldr == a.N)) {
+        !a.remap && a.ldc == a.N && a.bias != nullptr && a.R != nullptr && a.ldr == a.N) {   // (the fused row builder takes both as given)
       defer->part = a.partial; defer->nsplit = plan.s; defer->bias = a.bias; defer->resid = a.R; defer->alpha = a.alpha;
     } else if (plan.s > 1) {
       full.partial = a.partial;
@@ -539,15 +541,18 @@ int gam_finalize(gam_handle* h) {
         }
       }
     }
-    UP(h->mel_fb, fb);
-    std::vector<int> band(2 * (size_t)c.n_mels, 0);
+    std::vector<int> band(3 * (size_t)c.n_mels, 0);
+    std::vector<float> wts;
     for (int m = 0; m < c.n_mels; ++m) {
       int lo = nf, hi = 0;
       for (int f = 0; f < nf; ++f)
         if (fb[(size_t)f * c.n_mels + m] != 0.f) { lo = std::min(lo, f); hi = std::max(hi, f + 1); }
       if (hi <= lo) lo = hi = 0;
-      band[2 * m] = lo; band[2 * m + 1] = hi;
+      band[3 * m] = lo; band[3 * m + 1] = hi; band[3 * m + 2] = (int)wts.size();
+      for (int f = lo; f < hi; ++f) wts.push_back(fb[(size_t)f * c.n_mels + m]);
     }
+    h->mel_nw = (int)wts.size();
+    UP(h->mel_wts, wts);
     void* db = nullptr;
     if (hipMalloc(&db, band.size() * sizeof(int)) != hipSuccess) return fail(h, -2, "mel band upload failed");
     h->owned.push_back(db);
@@ -867,12 +872,12 @@ int gam_frontend(gam_handle* h, const float* wav, const int64_t* wav_len, int B,
   if (int r = gemm(h, s, g, GAM_ACT_NONE, GAM_PF_FRONTEND, nullptr)) return r;
   {
     GamPowMelArgs a;
-    a.spec = h->spec.p; a.fb = h->mel_fb; a.band = h->mel_band; a.feat = feat; a.wav_len = (const long long*)wav_len; a.feat_len = (long long*)feat_len;
+    a.spec = h->spec.p; a.wts = h->mel_wts; a.nw = h->mel_nw; a.band = h->mel_band; a.feat = feat; a.wav_len = (const long long*)wav_len; a.feat_len = (long long*)feat_len;
     a.B = B; a.Tfa = (int)Tfa; a.Tf = (int)Tf; a.nf = h->nf; a.n_mels = c.n_mels; a.lds = lds;
     a.hop = hop; a.win = c.win_length; a.center = c.center;
     ProfScope ps(h, s, GAM_PF_FRONTEND, (double)B * Tf * (2.0 * h->nf + c.n_mels) * 4.0);
     dim3 grid(gam_cdiv(Tf, 64), B);
-    hipLaunchKernelGGL(gam_powmel_kernel, grid, dim3(256), 64 * (h->nf + 1) * sizeof(float), s, a);
+    hipLaunchKernelGGL(gam_powmel_kernel, grid, dim3(256), (64 * (h->nf + 1) + h->mel_nw) * sizeof(float), s, a);
     HIPCHK(h, hipGetLastError());
   }
   return 0;

@@ -29,8 +29,9 @@ __global__ __launch_bounds__(256) void gam_pad_wav_kernel(const float* wav, floa
 
 struct GamPowMelArgs {
   const float* spec;   // [B*Tfa, lds]: re[0..nf) | im[nf..2nf)
-  const float* fb;     // [nf, n_mels]
-  const int* band;     // [2 * n_mels]: first / one-past-last frequency bin with a non-zero weight per mel band
+  const float* wts;    // the non-zero stretch of each band's filter (column of the [nf, n_mels] filterbank), band after band
+  int nw;              // floats in wts
+  const int* band;     // [3 * n_mels] per mel band: first / one-past-last bin with a non-zero weight, offset into wts
   float* feat;         // [B, n_mels, Tf]
   const long long* wav_len;  // [B] samples (may be null -> no feat_len output)
   long long* feat_len;       // [B]
@@ -40,7 +41,7 @@ struct GamPowMelArgs {
 
 // block: 64 frames x (n_mels <= 64) ; thread = (frame, 16 mel bands)
 __global__ __launch_bounds__(256) void gam_powmel_kernel(GamPowMelArgs a) {
-  extern __shared__ float gam_smem_pm[];   // [64][nf + 1]
+  extern __shared__ float gam_smem_pm[];   // power [64][nf + 1] | filter weights [nw]
   const int tid = threadIdx.x;
   const int b = blockIdx.y, t0 = blockIdx.x * 64;
   const int pld = a.nf + 1;
@@ -53,39 +54,53 @@ __global__ __launch_bounds__(256) void gam_powmel_kernel(GamPowMelArgs a) {
     a.feat_len[b] = qd + 1;
   }
   // power spectrum of the block's 64 frames: wave w takes frames w, w + 4, ..; a frame's bins are read lane-contiguous
-  // (no per-element index division; all loads of a frame in flight before the first use)
+  // (no per-element index division), FR frames = 8 FR loads per lane in flight before the first use -- at small batches the
+  // kernel is a chain of L2 / HBM round trips, one per group of frames
+  float* wl = gam_smem_pm + 64 * pld;   // the filter weights, staged once per block
+  for (int i = tid; i < a.nw; i += 256) wl[i] = a.wts[i];
   {
     const int lane = tid & 63, wv = tid >> 6;
-    for (int fl = wv; fl < 64; fl += 4) {
-      const int t = t0 + fl;
-      float* pr = gam_smem_pm + fl * pld;
-      if (t < a.Tf) {
+    constexpr int FR = 4;
+    for (int g = 0; g < 16; g += FR) {
+      float re[FR][4], im[FR][4];
+#pragma unroll
+      for (int q = 0; q < FR; ++q) {
+        const int fl = wv + 4 * (g + q);
+        int t = t0 + fl;
+        t = t < a.Tf ? t : a.Tf - 1;
         const float* sp = a.spec + ((size_t)b * a.Tfa + t) * a.lds;
-        float re[4], im[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int f = lane + 64 * u, fc = f < a.nf ? f : a.nf - 1;
-          re[u] = sp[fc];
-          im[u] = sp[a.nf + fc];
+          re[q][u] = sp[fc];
+          im[q][u] = sp[a.nf + fc];
         }
+      }
+#pragma unroll
+      for (int q = 0; q < FR; ++q) {
+        const int fl = wv + 4 * (g + q);
+        const bool in = t0 + fl < a.Tf;
+        float* pr = gam_smem_pm + fl * pld;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int f = lane + 64 * u;
-          if (f < a.nf) pr[f] = re[u] * re[u] + im[u] * im[u];
+          if (f < a.nf) pr[f] = in ? re[q][u] * re[q][u] + im[q][u] * im[q][u] : 0.f;
         }
-        for (int f = lane + 256; f < a.nf; f += 64) {   // (n_fft > 510: not a published configuration)
-          const float r2 = sp[f], i2 = sp[a.nf + f];
-          pr[f] = r2 * r2 + i2 * i2;
+        if (a.nf > 256) {   // (n_fft > 510: not a published configuration)
+          const float* sp = a.spec + ((size_t)b * a.Tfa + (in ? t0 + fl : a.Tf - 1)) * a.lds;
+          for (int f = lane + 256; f < a.nf; f += 64) {
+            const float r2 = sp[f], i2 = sp[a.nf + f];
+            pr[f] = in ? r2 * r2 + i2 * i2 : 0.f;
+          }
         }
-      } else {
-        for (int f = lane; f < a.nf; f += 64) pr[f] = 0.f;
       }
     }
   }
   __syncthreads();
   // mel projection: the filterbank is triangular (a bin feeds <= 2 bands), so each band sums only its
   // own bins, in increasing bin order like the dense product (zero terms dropped).  Bands are dealt
-  // round-robin to the 4 waves (m = 4 j + wave) so the wide high-frequency bands spread evenly.
+  // round-robin to the 4 waves (m = 4 j + wave) so the wide high-frequency bands spread evenly; both operands come from
+  // LDS (the weight address is wave-uniform: a broadcast read).
   const int fl = tid & 63, mg = tid >> 6;
   float acc[16];
   const float* pw = gam_smem_pm + fl * pld;
@@ -94,8 +109,9 @@ __global__ __launch_bounds__(256) void gam_powmel_kernel(GamPowMelArgs a) {
     const int m = 4 * j + mg;
     float s = 0.f;
     if (m < a.n_mels) {
-      const int f0 = a.band[2 * m], f1 = a.band[2 * m + 1];   // wave-uniform
-      for (int f = f0; f < f1; ++f) s = fmaf(pw[f], a.fb[(size_t)f * a.n_mels + m], s);
+      const int f0 = a.band[3 * m], f1 = a.band[3 * m + 1];   // wave-uniform
+      const float* wm = wl + a.band[3 * m + 2] - f0;
+      for (int f = f0; f < f1; ++f) s = fmaf(pw[f], wm[f], s);
     }
     acc[j] = s;
   }
