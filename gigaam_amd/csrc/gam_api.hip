@@ -54,12 +54,12 @@ struct W16 {            // split-fp16 planes of one weight matrix (gam_gemm16.h)
 
 struct LayerW {
   float *ln_ff1_w, *ln_ff1_b, *ff1_w1, *ff1_b1, *ff1_w2, *ff1_b2;
-  float *ln_att_w, *ln_att_b, *wqk, *bqk, *wv, *bv, *wo, *bo;
+  float *ln_att_w, *ln_att_b, *wqkv, *bqkv, *wo, *bo;   // rows [W_q; W_k; W_v]
   float *wpos, *pos_u, *pos_v;  // rel_pos only
   float *ln_conv_w, *ln_conv_b, *pw1_w, *pw1_b, *dw_w, *dw_b, *cn_scale, *cn_shift, *pw2_w, *pw2_b;
   float *ln_ff2_w, *ln_ff2_b, *ff2_w1, *ff2_b1, *ff2_w2, *ff2_b2;
   float *ln_out_w, *ln_out_b;
-  W16 s_ff1_w1, s_ff1_w2, s_wqk, s_wv, s_wo, s_wpos, s_pw1, s_pw2, s_ff2_w1, s_ff2_w2;
+  W16 s_ff1_w1, s_ff1_w2, s_wqkv, s_wo, s_wpos, s_pw1, s_pw2, s_ff2_w1, s_ff2_w2;
 };
 
 struct ProfEvent {
@@ -109,7 +109,7 @@ struct gam_handle {
   DevBuf rnnt_x;                // hand-off granules + status word of the cluster kernel
 
   // workspace (grow-only)
-  DevBuf wavp, spec, img, c2, xin, y1, x, y, yr, hbuf, qk, vbuf, ctx, ubuf, zbuf, tok, logits, encp, pbuf, aplanes;
+  DevBuf wavp, spec, img, c2, xin, y1, x, y, yr, hbuf, qkv, ctx, ubuf, zbuf, tok, logits, encp, pbuf, aplanes;
   int use_sp = 1;     // large-M GEMMs on the LDS-DMA sp32 kernel (GAM_SP=0 disables)
   int sp_min_m = GAM_SP_MIN_M;   // GAM_SP_MIN_M overrides (tests force the sp path at small sizes)
   DevBuf op_planes, op_sp, splitk_ws;   // gam_op_gemm operand planes; split-K partial sums
@@ -454,7 +454,7 @@ void gam_destroy(gam_handle* h) {
   hipSetDevice(h->device);
   for (void* p : h->owned) hipFree(p);
   DevBuf* bufs[] = {&h->wavp, &h->spec, &h->img, &h->c2, &h->xin, &h->y1, &h->x, &h->y, &h->yr, &h->hbuf,
-                    &h->qk, &h->vbuf, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes, &h->op_sp, &h->splitk_ws, &h->rsbuf, &h->op_rs, &h->rnnt_x};
+                    &h->qkv, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes, &h->op_sp, &h->splitk_ws, &h->rsbuf, &h->op_rs, &h->rnnt_x};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   if (h->lens) hipFree(h->lens);
@@ -655,14 +655,17 @@ int gam_finalize(gam_handle* h) {
       NEED(bq, p + "self_attn.linear_q.bias", D);
       NEED(wk, p + "self_attn.linear_k.weight", (int64_t)D * D);
       NEED(bk, p + "self_attn.linear_k.bias", D);
+      NEED(wv, p + "self_attn.linear_v.weight", (int64_t)D * D);
+      NEED(bv, p + "self_attn.linear_v.bias", D);
       std::vector<float> w(wq->data), b(bq->data);
       w.insert(w.end(), wk->data.begin(), wk->data.end());
+      w.insert(w.end(), wv->data.begin(), wv->data.end());
       b.insert(b.end(), bk->data.begin(), bk->data.end());
-      UP(L.wqk, w);
-      UP(L.bqk, b);
-      if (make_split(h, w, L.s_wqk, D)) return fail(h, -2, "split upload failed");
+      b.insert(b.end(), bv->data.begin(), bv->data.end());
+      UP(L.wqkv, w);
+      UP(L.bqkv, b);
+      if (make_split(h, w, L.s_wqkv, D)) return fail(h, -2, "split upload failed");
     }
-    LINS_(L.wv, L.bv, L.s_wv, "self_attn.linear_v", D, D);
     LINS_(L.wo, L.bo, L.s_wo, "self_attn.linear_out", D, D);
     if (c.self_attention_model == GAM_ATT_REL_POS) {
       NEED(wp, p + "self_attn.linear_pos.weight", (int64_t)D * D);
@@ -914,8 +917,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
   if (int r = ensure(h, h->y, (size_t)N * D)) return r;
   if (int r = ensure(h, h->yr, (size_t)N * D)) return r;
   if (int r = ensure(h, h->hbuf, (size_t)N * DFF)) return r;
-  if (int r = ensure(h, h->qk, (size_t)N * 2 * D)) return r;
-  if (int r = ensure(h, h->vbuf, (size_t)N * D)) return r;
+  if (int r = ensure(h, h->qkv, (size_t)N * 3 * D)) return r;
   if (int r = ensure(h, h->ctx, (size_t)N * D)) return r;
   if (int r = ensure(h, h->ubuf, (size_t)N * 2 * D)) return r;
   if (int r = ensure(h, h->zbuf, (size_t)N * D)) return r;
@@ -1023,13 +1025,26 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       a.x = h->x.p; a.out1 = h->y.p; a.out2 = h->yr.p; a.w1 = L.ln_att_w; a.b1 = L.ln_att_b;
       a.split1 = sp; a.split2 = sp;
       if (int r = layernorm(h, s, a, rel ? 0 : 1, &pend)) return r;
-      // rotary: q,k project the rotated copy, v the plain one; rel_pos: all three project y
-      GamGemmArgs gq = gemm_args(rel ? h->y.p : h->yr.p, D, L.wqk, L.bqk, h->qk.p, 2 * D, N, 2 * D, D);
-      sp_a(gq); gq.a_rs = rs; gq.c_guard = 1;   // q, k and v are split to fp16 unscaled by the attention kernel
-      if (int r = gemm(h, s, gq, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wqk)) return r;
-      GamGemmArgs gv = gemm_args(h->y.p, D, L.wv, L.bv, h->vbuf.p, D, N, D, D);
-      sp_a(gv); gv.a_rs = rs; gv.c_guard = 1;
-      if (int r = gemm(h, s, gv, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wv)) return r;
+      // rotary: q,k project the rotated copy, v the plain one; rel_pos: all three project y.  One [N, 3D] result q | k | v.
+      // q, k and v are split to fp16 unscaled by the attention kernel: range guard on all of them.
+      const bool one_launch = rel || (sp && (2 * D) % 256 == 0);   // (the operand switch sits on a tile boundary of either tile width)
+      if (one_launch) {
+        GamGemmArgs gq = gemm_args(rel ? h->y.p : h->yr.p, D, L.wqkv, L.bqkv, h->qkv.p, 3 * D, N, 3 * D, D);
+        sp_a(gq); gq.a_rs = rs; gq.c_guard = 1;
+        if (!rel) { gq.Asp2 = reinterpret_cast<const _Float16*>(h->y.p); gq.n_switch = 2 * D; }
+        if (int r = gemm(h, s, gq, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wqkv)) return r;
+      } else {
+        GamGemmArgs gq = gemm_args(h->yr.p, D, L.wqkv, L.bqkv, h->qkv.p, 3 * D, N, 2 * D, D);
+        sp_a(gq); gq.a_rs = rs; gq.c_guard = 1;
+        if (int r = gemm(h, s, gq, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wqkv)) return r;
+        W16 wv16 = L.s_wqkv;   // rows 2D .. 3D of the same planes
+        const size_t off = (size_t)2 * D * D;
+        if (wv16.hi) { wv16.hi += off; wv16.lo += off; }
+        if (wv16.sp) wv16.sp += 2 * off;
+        GamGemmArgs gv = gemm_args(h->y.p, D, L.wqkv + off, L.bqkv + 2 * D, h->qkv.p + 2 * D, 3 * D, N, D, D);
+        sp_a(gv); gv.a_rs = rs; gv.c_guard = 1;
+        if (int r = gemm(h, s, gv, GAM_ACT_NONE, GAM_PF_GEMM, &wv16)) return r;
+      }
       if (rel) {  // P = linear_pos(pos_emb) for relative positions -(T'-1) .. T'-1 (no bias)
         const float* pe0 = h->rel_pe + (size_t)(c.pos_emb_max_len - 1 - (Tv - 1)) * D;
         GamGemmArgs gp = gemm_args(pe0, D, L.wpos, nullptr, h->pbuf.p, D, 2 * Tv - 1, D, D);
@@ -1037,9 +1052,9 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       }
       GamAttnArgs at;
       memset(&at, 0, sizeof at);
-      at.q = h->qk.p; at.k = h->qk.p + D; at.v = h->vbuf.p; at.ctx = h->ctx.p; at.ctx_split = sp;
+      at.q = h->qkv.p; at.k = h->qkv.p + D; at.v = h->qkv.p + 2 * D; at.ctx = h->ctx.p; at.ctx_split = sp;
       at.lens = B > 1 ? len2 : nullptr;  // encoder.py:620-624: no mask at batch 1
-      at.B = B; at.Ta = Ta; at.Tv = Tv; at.H = H; at.ldq = 2 * D; at.ldv = D; at.ldo = D;
+      at.B = B; at.Ta = Ta; at.Tv = Tv; at.H = H; at.ldq = 3 * D; at.ldv = 3 * D; at.ldo = D;
       at.scale = 1.0f / sqrtf((float)dk);
       at.pbuf = rel ? h->pbuf.p : nullptr; at.pos_u = L.pos_u; at.pos_v = L.pos_v; at.ldp = D;
       {

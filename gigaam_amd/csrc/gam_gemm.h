@@ -56,6 +56,10 @@ struct GamGemmArgs {
   // both operands in the sp32 layout of gam_gemm_sp.h (row pitch = lda / K elements, 4 B each)
   const _Float16* Asp;
   const _Float16* Wsp;
+  // gam_gemm_sp.h only: output columns n >= n_switch (> 0, a multiple of the tile width) contract Asp2 instead of Asp -- one
+  // launch for two projections of two operands that share rows, pitch and row scale (q|k of the rotated copy, v of the plain one)
+  const _Float16* Asp2;
+  int n_switch;
   int c_split;          // write C in the sp32 layout (row pitch ldc elements) instead of fp32
   // split-K (small grids): grid.y = splitk slices of K; this struct's K is the slice length, ldw the
   // full row pitch of W; slice s reads columns [s*K, (s+1)*K) and writes its raw partial sums to

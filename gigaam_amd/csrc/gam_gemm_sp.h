@@ -102,7 +102,7 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
     return ((size_t)fr * 2 * g.conv_fp + 2 * ff) * (size_t)g.conv_c;
   };
   const size_t a_tile0 = a_row_off(m0);   // offsets grow with m, so every row offset is >= this one
-  const unsigned char* Ab = reinterpret_cast<const unsigned char*>(g.Asp) + a_tile0 * 4;
+  const unsigned char* Ab = reinterpret_cast<const unsigned char*>(g.n_switch > 0 && n0 >= g.n_switch ? g.Asp2 : g.Asp) + a_tile0 * 4;
   const unsigned char* Wb = reinterpret_cast<const unsigned char*>(g.Wsp) + (size_t)n0 * (size_t)g.K * 4;
   unsigned a_src[NAI], w_src[NWI];
 #pragma unroll
@@ -464,6 +464,7 @@ static inline hipError_t gam_launch_gemm_sp(const GamGemmArgs& a_in, int act, hi
     if (a.splitk > 1 && a.partial == nullptr) return hipErrorInvalidValue;
   }
   if (a.splitk > 1 && (a.partial == nullptr || (a.K / 32) % a.splitk != 0)) return hipErrorInvalidValue;
+  if (a.n_switch > 0 && (a.Asp2 == nullptr || a.a_mode != 0 || a.n_switch % (64 * nw) != 0)) return hipErrorInvalidValue;
   if (a.splitk <= 1) { a.splitk = 0; a.partial = nullptr; }
   const int grid = gam_cdiv(a.M, 64 * mt) * gam_cdiv(a.N, 64 * nw);
   a.ntiles = grid;
