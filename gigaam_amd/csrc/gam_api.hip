@@ -319,7 +319,7 @@ int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls
   if (ps.ev) {   // unique bytes: A (overlapping rows counted once), W, C (+ residual)
     const double abytes = a.a_mode == 0 ? ((double)(a.M - 1) * (double)std::min<long>(a.lda, a.K) + a.K) * 4.0
                                         : (double)a.M / a.conv_f2 * 2.0 * a.conv_fp * a.conv_c * 4.0;
-    h->prof_bytes[cls] += abytes + 4.0 * a.N * a.K + 4.0 * a.M * a.N * (a.R ? 2.0 : 1.0);
+    h->prof_bytes[cls] += abytes * (a.n_switch > 0 ? 2.0 : 1.0) + 4.0 * a.N * a.K + 4.0 * a.M * a.N * (a.R ? 2.0 : 1.0);   // (n_switch: two A operands)
   }
   hipError_t e;
   const bool f16 = h->gemm_mode == 1 && w16 != nullptr && w16->hi != nullptr;

@@ -73,7 +73,7 @@ void gam_destroy(gam_handle* h);
 int gam_set_weight(gam_handle* h, const char* key, const void* host_ptr, int dtype,
                    const int64_t* shape, int ndim);
 
-/* Validate the key set, re-lay weights for the kernels (fused q|k, channels-last conv
+/* Validate the key set, re-lay weights for the kernels (fused q|k|v, channels-last conv
  * taps, folded BatchNorm, DFT basis, rotary table, LSTM input table) and upload. */
 int gam_finalize(gam_handle* h);
 
