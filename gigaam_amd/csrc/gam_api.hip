@@ -880,7 +880,13 @@ int gam_frontend(gam_handle* h, const float* wav, const int64_t* wav_len, int B,
     a.hop = hop; a.win = c.win_length; a.center = c.center;
     ProfScope ps(h, s, GAM_PF_FRONTEND, (double)B * Tf * (2.0 * h->nf + c.n_mels) * 4.0);
     dim3 grid(gam_cdiv(Tf, 64), B);
-    hipLaunchKernelGGL(gam_powmel_kernel, grid, dim3(256), (64 * (h->nf + 1) + h->mel_nw) * sizeof(float), s, a);
+    const size_t pm_lds = (size_t)(64 * (h->nf + 1) + h->mel_nw) * sizeof(float);
+    if (pm_lds > 160 * 1024) return fail(h, -1, "n_fft %d: the power / mel kernel's LDS image (%zu bytes) does not fit", c.n_fft, pm_lds);
+    if (pm_lds > 64 * 1024) {   // (n_fft > 500; the published frontends need 53 KB)
+      static std::atomic<unsigned long long> attr_devs{0};
+      HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_powmel_kernel), (int)pm_lds, attr_devs));
+    }
+    hipLaunchKernelGGL(gam_powmel_kernel, grid, dim3(256), pm_lds, s, a);
     HIPCHK(h, hipGetLastError());
   }
   return 0;
