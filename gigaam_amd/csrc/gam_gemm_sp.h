@@ -274,7 +274,7 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
     phase(C1_{}, T_{}, sn, o_h0, o_l0, kt & 1);
     if (GAM_SP_DBG(g) & 4) { c3 = clock64(); t_mm0 += c1 - c0; t_bar += c2 - c1; t_mm1 += c3 - c2; }
   }
-  if ((GAM_SP_DBG(g) & 4) && lane == 0 && (lid == 0 || lid == gridDim.x - 1)) {
+  if ((GAM_SP_DBG(g) & 4) && lane == 0 && (lid == 0 || lid == (int)gridDim.x - 1)) {
     // [total clk, total wall(100 MHz), phase 0, barrier, phase 1] of one wave
     float* d = g.C + (size_t)(g.M - 1) * g.ldc + (lid == 0 ? 0 : 64) + wave * 8;
     d[0] = (float)(clock64() - t_start); d[1] = (float)(wall_clock64() - w_start);
