@@ -15,8 +15,9 @@ gather of the decoded (index, counts, ids, frames) over RCCL (gam_gather_ids, in
   config 1  v2_ctc, one 5 s clip
   config 4  v3_e2e_rnnt (V = 1025), 128 utterances per GPU (weak; 1024 at 8 GPUs) or 1024 in total (strong),
             durations U(5 s, 20 s), sorted into 32-utterance batches dealt to the ranks
-  config 5  v2_ctc longform: 1 h of audio, the reference's chunk packer, batches of 16 dealt round-robin to
-            the ranks and streamed through the pinned double-buffered feeder (always strong scaling)
+  config 5  v2_ctc longform: 1 h of audio, the reference's chunk packer, the chunks dealt by duration (LPT) to the ranks,
+            each rank's share in length-sorted batches of 16 streamed through the pinned double-buffered feeder (always
+            strong scaling; the file order is restored in the result)
 --scaling weak: per-GPU work fixed (32 utterances per GPU); strong: the global batch of 32 split over the ranks.
 
 Utterances are independent, so ranks own disjoint utterances with replicated weights.  Weights are random-init
@@ -271,6 +272,10 @@ def cpu_baseline(ckpt, wav, wlen, n_utts: int, gpu_decoded, sweep: bool):
     rp = os.path.join(ROOT, "profiles", "r03_cpu_ref_vs_port.json")
     if os.path.exists(rp):   # the reference's own modules timed beside this port in the build container (tools/cpu_ref_vs_port.py)
         rj = json.load(open(rp))
+        out["reference_rtfx_build_container"] = rj["reference_rtfx"]
+        out["port_rtfx_build_container"] = rj["port_rtfx"]
+        out["port_over_reference"] = rj["port_over_reference"]
+        out["reference_build_container_threads"] = rj["threads"]
         out["note"] = (f"reference modules vs this port on the same {rj['utterances']} utterances, {rj['threads']} threads, build container: "
                        f"reference {rj['reference_rtfx']}x, port {rj['port_rtfx']}x real time (port/reference = {rj['port_over_reference']}); "
                        "profiles/r03_cpu_ref_vs_port.json")
@@ -391,6 +396,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--no-power", action="store_true", help="skip the board power / shader clock sampling leg")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the exact-fp32 re-timing (roofline_f32_exact)")
+    ap.add_argument("--no-h2d-leg", action="store_true", help="skip the host-memory re-timing (h2d_ms)")
     ap.add_argument("--gemm", default="f16x3", choices=["f16x3", "f32"],
                     help="dense-contraction arithmetic: split-fp16 MFMA (fp32-equivalent, default) or exact fp32 MFMA")
     ap.add_argument("--launch-selftest", action="store_true", help="CPU-only check of the rank plumbing (gloo); no GPU work")
@@ -484,16 +490,14 @@ def main():
                 ids = frames = torch.zeros((0, cap0), dtype=torch.int32, device=dev)
                 counts = torch.zeros((0,), dtype=torch.int32, device=dev)
             if n_ranks > 1:
-                pad = rows - ids.shape[0]
-                if pad:
-                    ids = torch.cat([ids, ids.new_zeros((pad, ids.shape[1]))])
-                    frames = torch.cat([frames, frames.new_zeros((pad, frames.shape[1]))])
-                    counts = torch.cat([counts, counts.new_zeros((pad,))])
-                if eng.range_flag():                       # (N > 1: this rank's flag, before its rows leave for the other ranks)
-                    raise RuntimeError("split-fp16 range flag set during a bench step")
-                gi, gc, gids, gfr = gather(idx_dev, counts, ids, frames)
-                keep = gi >= 0
-                ids, frames, counts = gids[keep], gfr[keep], gc[keep]
+                # this rank's range flag rides in the exchange as one extra row (shard.append_flag_row): the padding, the
+                # gather and the row selection below all drop the hidden tail word of `counts`, and a separate
+                # eng.range_flag() here would read a flag the decode call has already consumed
+                gi, gc, gids, gfr = gather(*shard.append_flag_row(idx_dev, counts, ids, frames, shard.range_flag_of(counts), rows))
+                dec, _, flag = shard.collect_gathered(gi, gc, gids, gfr)
+                if flag:
+                    raise RuntimeError("split-fp16 range flag set on some rank during a bench step")
+                return dec
             return ragged_host(ids, frames, counts)        # the decoded ids (+ the range flag at N = 1) end every step on the host
         workload = (f"{model_name} (16-layer Conformer, random-init weights), {n_global} x {seconds:g} s 16 kHz utterances "
                     f"({'%d per GPU' % args.batch if scaling == 'weak' else 'global batch split over the ranks'}), frontend + encoder + "
@@ -520,11 +524,18 @@ def main():
         from gigaam_amd.feeder import BatchFeeder
         segs, bounds = workloads.config5_segments(args.longform_seconds)
         fr_bs = args.fr_batch
-        n_b = (len(segs) + fr_bs - 1) // fr_bs
-        mine = shard.deal(n_b, rank, n_ranks, snake=False)      # round-robin, in file order
-        my_segs = [s for j in mine for s in segs[j * fr_bs:(j + 1) * fr_bs]]
-        my_idx = [i for j in mine for i in range(j * fr_bs, min(len(segs), (j + 1) * fr_bs))]
-        per_rank = max(sum(min(len(segs), (j + 1) * fr_bs) - j * fr_bs for j in shard.deal(n_b, r, n_ranks, snake=False)) for r in range(n_ranks))
+        # Who decodes what: CHUNKS (not batches) are dealt by duration, longest first, each to the rank with the least audio so
+        # far (shard.lpt_deal), and every rank cuts its own share -- already sorted by length -- into batches of fr_batch_size.
+        # Every rank gets the same audio seconds (194 chunks on 8 ranks: max / min = 1.02; dealing whole file-order batches
+        # round-robin gave 2,2,2,2,2,1,1,1 batches = a 6.5x ceiling) and every batch holds chunks of
+        # neighbouring lengths.  The file order of the reference's loop (gigaam/model.py:219-258) is restored in the result.
+        costs = [int(x.shape[0]) for x in segs]
+        all_rank_batches = shard.rank_batches(costs, n_ranks, fr_bs)
+        my_batches = all_rank_batches[rank]
+        my_idx = [i for b in my_batches for i in b]
+        my_segs = [segs[i] for i in my_idx]
+        per_rank = max(sum(len(b) for b in rb) for rb in all_rank_batches)
+        rank_audio = [sum(costs[i] for b in rb for i in b) / 16000.0 for rb in all_rank_batches]
         cap = eng.enc_frames(eng.feat_frames(30 * 16000 + 160))
         audio_s = float(args.longform_seconds)
         tok = model.decoding.tokenizer
@@ -532,17 +543,15 @@ def main():
         feeder = BatchFeeder(my_segs, fr_bs, dev) if my_segs else []       # pinned staging buffers: allocated once
         last5 = {}
         if rank == 0:
-            # CPU-oracle leg: four rows of the batch that holds the file's longest chunk, cut from that batch's OWN zero-padded
-            # tensor -- the reference's features of an utterance's last frames depend on what follows it in its row (zero
-            # padding inside a batch, reflect padding at the end of the longest row: torchaudio center=True pads the TENSOR),
-            # so the oracle must see each chunk exactly as the GPU's batch held it, not re-collated with other neighbours
+            # CPU-oracle leg: four rows of the batch that holds the file's longest chunk (rank 0's first batch: LPT deals the
+            # longest chunk first, to rank 0), cut from that batch's OWN zero-padded tensor -- the reference's features of an
+            # utterance's last frames depend on what follows it in its row (zero padding inside a batch, reflect padding at the
+            # end of the longest row: torchaudio center=True pads the TENSOR), so the oracle must see each chunk exactly as the
+            # GPU's batch held it, not re-collated with other neighbours
             from gigaam_amd.feeder import collate
-            order = sorted(range(len(segs)), key=lambda i: -int(segs[i].shape[0]))
-            jb = order[0] // fr_bs
-            rows5 = list(range(jb * fr_bs, min(len(segs), (jb + 1) * fr_bs)))
+            rows5 = list(my_batches[0])
             w5, l5 = collate([segs[i] for i in rows5])
-            r0 = order[0] - jb * fr_bs
-            sel = [r0] + [r for r in sorted(range(len(rows5)), key=lambda r: -int(l5[r])) if r != r0][:3]
+            sel = sorted(range(len(rows5)), key=lambda r: -int(l5[r]))[:4]
             cpu_sample = (w5[sel].contiguous(), l5[sel].contiguous(), [rows5[r] for r in sel])
 
         trace = os.environ.get("GAM_BENCH_TRACE")   # debug: host timestamps per batch (ms since the step began)
@@ -567,8 +576,11 @@ def main():
             last5["res"] = res
             return res if rank != 0 else [(tok.decode(i), bounds[k]) for k, (i, f) in enumerate(res)]
         workload = (f"{model_name} longform: {args.longform_seconds} s of audio -> {len(segs)} chunks (reference packer 22/15/30/0.2 s) -> "
-                    f"batches of {fr_bs} dealt round-robin to {n_ranks} rank(s), streamed from host memory through the pinned "
-                    "double-buffered feeder, CTC greedy, gather, detokenise")
+                    f"chunks dealt by duration (LPT) to {n_ranks} rank(s), each rank's share in length-sorted batches of {fr_bs} "
+                    f"({len(my_batches)} batches on rank 0; audio seconds per rank max/min = {max(rank_audio) / max(1e-9, min(rank_audio)):.3f}), "
+                    "streamed from host memory through the pinned double-buffered feeder, CTC greedy, gather, detokenise, file order restored")
+        dealing = {"audio_seconds_per_rank": [round(a, 1) for a in rank_audio], "chunks_per_rank": [sum(len(b) for b in rb) for rb in all_rank_batches],
+                   "dealing_bound_speedup": round(sum(rank_audio) / max(rank_audio), 3)}
 
     # ---- timing: W warm-up steps, then EXACTLY K steps between barrier + synchronize pairs; max over ranks
     # Per-launch HIP-event pairs around the GEMM family INSIDE the timed region (the roofline's launch durations), on every
@@ -616,6 +628,50 @@ def main():
         power = ps.summary()
         power["steps_sampled"] = n_pw
 
+    # host-memory leg (config 2, one rank): the same step with the waveform starting in HOST memory -- never `value` (the
+    # contract times inputs resident in HBM), reported next to it.  "serial": one pinned -> device copy on the launch stream in
+    # front of every step; "feeder": the product's longform feeding path (feeder.BatchFeeder: the batch is assembled in a
+    # pinned staging buffer and copied on a side stream while the previous step's kernels run).
+    h2d_leg = None
+    if n_ranks == 1 and cfgno == 2 and not args.no_h2d_leg:
+        from gigaam_amd.feeder import BatchFeeder
+        wav_pin, len_pin = wav_h.pin_memory(), wlen_h.pin_memory()
+        k_h = max(3, min(args.steps, 10))
+
+        def step_serial():
+            w = torch.empty(wav_pin.shape, dtype=wav_pin.dtype, device=dev)
+            w.copy_(wav_pin, non_blocking=True)
+            return ragged_host(*decode_dev(w, len_pin.to(dev, non_blocking=True)))
+        step_serial()
+        barrier_sync()
+        t0 = time.perf_counter()
+        for _ in range(k_h):
+            step_serial()
+        barrier_sync()
+        t_serial = (time.perf_counter() - t0) / k_h
+        utt_h = [wav_h[i] for i in range(wav_h.shape[0])]
+
+        def run_feeder(k):
+            pending, n_done = None, 0
+            for wb, lb in BatchFeeder(utt_h * k, len(utt_h), dev):
+                out_b = decode_dev(wb, lb)
+                if pending is not None:
+                    ragged_host(*pending); n_done += 1
+                pending = out_b
+            ragged_host(*pending)
+            return n_done + 1
+        run_feeder(2)
+        barrier_sync()
+        t0 = time.perf_counter()
+        n_b = run_feeder(k_h)
+        barrier_sync()
+        t_feed = (time.perf_counter() - t0) / n_b
+        h2d_leg = {"ms_per_step_serial_copy": round(t_serial * 1e3, 3), "ms_per_step_feeder": round(t_feed * 1e3, 3), "steps": k_h,
+                   "h2d_bytes_per_step": int(wav_h.numel() * 4),
+                   "note": "waveform starts in host memory; serial = pinned->device copy on the launch stream before every step; "
+                           "feeder = gigaam_amd.feeder.BatchFeeder (batch collated into a pinned staging buffer, side-stream copy "
+                           "under the previous step, ids of step n collected after step n+1 is launched)"}
+
     # exact-fp32 leg: the same steps with the dense contractions on v_mfma_f32_32x32x2_f32 (the reference's arithmetic)
     f32_leg = None
     if args.gemm == "f16x3" and not args.no_f32_leg and cfgno in (2, 3):
@@ -655,6 +711,9 @@ def main():
         "config": {"workload": workload, "baseline_config": cfgno, "audio_seconds_per_step": round(audio_s, 1),
                    "parallelism": f"dp{n_ranks} (utterance shards, replicated weights, one exchange: {gather_name})"},
     }
+    line["gather_path"] = gather_name        # (top level: a silent fall-back to torch.distributed on the 8-GPU node must be visible)
+    if cfgno == 5:
+        line["config"]["dealing"] = dealing
     if n_units:
         line["config"]["global_batch"] = n_units * (n_ranks if scaling == "weak" else 1)
         line["encoder_ms_per_utt"] = round(ms_step / max(1, (g1 - g0)), 4)
@@ -723,6 +782,9 @@ def main():
             r = line["roofline"]
             r["avg_sclk_mhz_under_load"] = power["avg_sclk_mhz"]
             r["frac_at_measured_clock"] = round(r["frac"] * PEAK_SCLK_MHZ / power["avg_sclk_mhz"], 4)
+    if h2d_leg is not None:
+        line["h2d_ms"] = h2d_leg["ms_per_step_feeder"]
+        line["h2d"] = h2d_leg
     if f32_leg is not None:
         dt32, out32, p32 = f32_leg
         leg = {"ms_per_step": round(dt32 / args.steps * 1e3, 3), "value": round(audio_s * args.steps / dt32, 1),

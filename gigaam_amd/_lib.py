@@ -59,6 +59,8 @@ SIGNATURES = {
     "gam_op_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "gam_tune_sp": (C.c_int, [C.c_int, C.c_int, C.c_int]),
     "gam_plan_sp": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gam_plan_sp_ex": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gam_tune_sp_stages": (C.c_int, [C.c_int]),
     "gam_profile_enable": (C.c_int, [_P, C.c_int]),
     "gam_profile_pause": (C.c_int, [_P, C.c_int]),
     "gam_profile_read": (C.c_int, [_P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),

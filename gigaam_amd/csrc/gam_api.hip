@@ -299,19 +299,34 @@ struct ProfScope {
   }
 };
 
-// A split-K reduce left to the consumer: the LayerNorm that follows a residual GEMM sums the slices itself (gam_norm.h)
+// A split-K reduce left to the consumer: the LayerNorm that follows a residual GEMM sums the slices itself (gam_norm.h).
+// The record carries everything the stand-alone reduce pass would need (`full` + `act`), so a consumer that does not match
+// what was deferred -- another x, another shape, a GEMM launched in between -- gets the reduce kernel instead of stale sums.
 struct PendingReduce {
   const float* part = nullptr;
   int nsplit = 0;
   const float* bias = nullptr;
   const float* resid = nullptr;
   float alpha = 1.0f;
+  GamGemmArgs full;     // the GEMM as launched without split-K: C / M / N / ldc identify the consumer that may fuse
+  int act = 0;
+  void clear() { part = nullptr; nsplit = 0; }
 };
+
+// run the deferred reduce as its own pass (the fall-back of every path that cannot fuse it)
+int flush_pending(gam_handle* h, hipStream_t s, PendingReduce* p) {
+  if (p == nullptr || p->part == nullptr) return 0;
+  const hipError_t e = gam_launch_splitk_reduce(p->full, p->act, p->nsplit, s);
+  const int M = p->full.M, N = p->full.N;
+  p->clear();
+  if (e != hipSuccess) return fail(h, -2, "split-K reduce launch (M=%d N=%d): %s", M, N, hipGetErrorString(e));
+  return 0;
+}
 
 int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls = GAM_PF_GEMM, const W16* w16 = nullptr,
          PendingReduce* defer = nullptr) {
   GamGemmArgs a = a_in;
-  if (defer) *defer = PendingReduce();
+  if (int r = flush_pending(h, s, defer)) return r;   // (an unconsumed deferral must not be overwritten: its C would stay unreduced)
   a.range_flag = h->use_range ? h->range_flag : nullptr;
   if (h->gemm_mode != GAM_GEMM_F16X3) a.c_guard = 0;   // fp32 consumers have no range limit
   if (h->gemm_mode != GAM_GEMM_F16X3 || w16 == nullptr || w16->hi == nullptr) a.a_rs = nullptr;   // exact-fp32 path: A is never scaled
@@ -327,8 +342,9 @@ int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls
     if (w16->sp == nullptr) return fail(h, -2, "sp32 A without sp32 W planes");
     a.Whi = w16->hi; a.Wlo = w16->lo; a.wscale_inv = w16->inv;
     a.Wsp = w16->sp;
-    const GamSpPlan plan = gam_gemm_sp_plan(a.M, a.N, a.K, a.a_mode, h->ncu);
-    a.sp_mt = plan.mt; a.sp_nw = plan.nw;
+    GamSpPlan plan = gam_gemm_sp_plan(a.M, a.N, a.K, a.a_mode, h->ncu);
+    if (!h->use_splitk) plan.s = 1;   // GAM_SPLITK=0: the A/B switch covers this path too (tile shape as planned)
+    a.sp_mt = plan.mt; a.sp_nw = plan.nw; a.sp_ns = plan.ns;
     GamGemmArgs full = a;
     if (plan.s > 1) {   // small grid: S slices of K leave partial sums, the reduce pass applies the epilogue
       if (int r = ensure(h, h->splitk_ws, (size_t)plan.s * a.M * a.N + 64)) return r;
@@ -339,6 +355,7 @@ int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls
     if (plan.s > 1 && defer != nullptr && h->fuse_reduce && act == GAM_ACT_NONE && !a.c_split && !a.c_guard && a.lens == nullptr &&
         !a.remap && a.ldc == a.N && a.bias != nullptr && a.R != nullptr && a.ldr == a.N) {   // (the fused row builder takes both as given)
       defer->part = a.partial; defer->nsplit = plan.s; defer->bias = a.bias; defer->resid = a.R; defer->alpha = a.alpha;
+      defer->full = full; defer->full.partial = a.partial; defer->act = act;
     } else if (plan.s > 1) {
       full.partial = a.partial;
       e = gam_launch_splitk_reduce(full, act, plan.s, s);
@@ -387,10 +404,17 @@ GamGemmArgs gemm_args(const float* A, long lda, const float* W, const float* bia
   return g;
 }
 
-int layernorm(gam_handle* h, hipStream_t s, GamLnArgs a, int mode, const PendingReduce* pend = nullptr) {
+int layernorm(gam_handle* h, hipStream_t s, GamLnArgs a, int mode, PendingReduce* pend = nullptr) {
   if (pend != nullptr && pend->part != nullptr) {
-    a.part = pend->part; a.nsplit = pend->nsplit; a.pbias = pend->bias; a.presid = pend->resid; a.palpha = pend->alpha;
-    a.xstore = const_cast<float*>(a.x);
+    // fuse only what was deferred for THIS consumer: the LayerNorm's input is the GEMM's C, same rows x columns, dense
+    const GamGemmArgs& g = pend->full;
+    if (a.x == g.C && a.rows == g.M && a.d == g.N && g.ldc == g.N) {
+      a.part = pend->part; a.nsplit = pend->nsplit; a.pbias = pend->bias; a.presid = pend->resid; a.palpha = pend->alpha;
+      a.xstore = const_cast<float*>(a.x);
+      pend->clear();     // consumed: nothing may fuse (or flush) these slices again
+    } else if (int r = flush_pending(h, s, pend)) {
+      return r;
+    }
   }
   const double bytes = (double)a.rows * a.d * 4.0 * (mode == 0 ? 2.0 : 3.0);
   ProfScope ps(h, s, GAM_PF_NORM, bytes);
@@ -421,6 +445,7 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   if (const char* e = getenv("GAM_SPLITK")) h->use_splitk = atoi(e);
   if (const char* e = getenv("GAM_FUSE_REDUCE")) h->fuse_reduce = atoi(e);
   if (const char* e = getenv("GAM_GRAPH")) h->use_graph = atoi(e);
+  if (const char* e = getenv("GAM_GRAPH_MAX_ROWS")) h->graph_max_rows = atoi(e);
   if (const char* e = getenv("GAM_RNNT_CLUSTER")) h->rnnt_cluster = atoi(e);
   if (const char* e = getenv("GAM_RNNT_COOP")) h->rnnt_coop = atoi(e);
   if (const char* e = getenv("GAM_RNNT_FORCE_TIMEOUT")) h->rnnt_force_timeout = atoi(e);
@@ -1124,7 +1149,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       }
     }
   }
-  return 0;
+  return flush_pending(h, s, &pend);   // (nothing is pending after a norm_out; kept so that a future reordering cannot lose a reduce)
   };
 
   // Small batches: replay the layer sequence as one hipGraph (see gam_handle::use_graph).
@@ -1132,7 +1157,8 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
   if (h->use_graph && !h->prof_on && nl > 0 && N < h->graph_max_rows) {
     // every workspace the captured launches touch must exist before the capture (no allocation inside)
     if (int r = ensure(h, h->splitk_ws, (size_t)16 * N * std::max(DFF, 2 * D) + 64)) return r;
-    const std::vector<int> key = {B, Ta, Tv, nl, h->gemm_mode, (int)sp, h->use_splitk};
+    const GamSpForce& frc = gam_sp_force();   // (a plan forced through gam_tune_sp after a capture must not replay the old tiling)
+    const std::vector<int> key = {B, Ta, Tv, nl, h->gemm_mode, (int)sp, h->use_splitk, h->fuse_reduce, frc.mt.load(), frc.nw.load(), frc.s.load(), frc.ns.load()};
     gam_handle::GraphEntry& ge = h->graphs[key];
     if (ge.gen != h->ws_generation) {   // a buffer moved since this entry was made
       if (ge.exec) { hipGraphExecDestroy(ge.exec); --h->graph_count; }
@@ -1464,7 +1490,21 @@ int gam_plan_sp(int M, int N, int K, int n_cu, int* mt, int* nw, int* splitk) {
 }
 
 int gam_tune_sp(int mt, int nw, int splitk) {
-  g_gam_sp_force[0] = mt; g_gam_sp_force[1] = nw; g_gam_sp_force[2] = splitk;
+  GamSpForce& f = gam_sp_force();
+  f.mt = mt; f.nw = nw; f.s = splitk;
+  return 0;
+}
+
+int gam_tune_sp_stages(int stages) {
+  if (stages != 0 && stages != 2 && stages != 3) return -1;
+  gam_sp_force().ns = stages;
+  return 0;
+}
+
+int gam_plan_sp_ex(int M, int N, int K, int n_cu, int* mt, int* nw, int* splitk, int* stages) {
+  if (M <= 0 || N <= 0 || K <= 0 || K % 32 != 0 || !mt || !nw || !splitk || !stages) return -1;
+  const GamSpPlan p = gam_gemm_sp_plan(M, N, K, 0, n_cu > 0 ? n_cu : 256);
+  *mt = p.mt; *nw = p.nw; *splitk = p.s; *stages = p.ns;
   return 0;
 }
 

@@ -17,8 +17,10 @@
 //     exchange counter, buffers alternate by parity, so a granule is never rewritten before every member has
 //     read it (an all-gather cannot complete before all members have written, i.e. finished the previous one).
 //   * every spin is bounded (wall clock): a member that gives up sets the launch's status word, its cluster
-//     unwinds, and counts[b] = -1 tells the host (the Python shim raises) -- a workgroup that was not resident
-//     cannot hang the GPU.  The launcher sizes the grid to <= one workgroup per CU.
+//     unwinds and leaves counts[b] = -1 -- a workgroup that was not resident cannot hang the GPU.  The launcher sizes
+//     the grid to <= one workgroup per CU, and gam_rnnt_greedy enqueues a repair pass behind every cluster launch (the
+//     one-workgroup kernel with only_failed: its workgroups return at once unless their utterance was left at -1), so
+//     the caller gets the reference's ids either way -- no host round trip, nothing raises.
 // Tried and dropped (r02_s6): W_pred by COLUMN slices, each member publishing the partial product of its own h' slice so
 // that the h' gather and the pp reduction share one hand-off -- C x JH granules per step instead of JH made it slower
 // (config 3 decode 4.57 vs 4.13 ms).

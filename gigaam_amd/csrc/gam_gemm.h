@@ -68,6 +68,7 @@ struct GamGemmArgs {
   long ldw;             // row pitch of W / Whi / Wlo in elements (0 = K)
   float* partial;
   int sp_mt, sp_nw;     // LDS-DMA GEMM: the plan's tile shape (gam_gemm_sp_plan); 0 = let the launcher plan (no split-K)
+  int sp_ns;            // LDS stages of the plan (2 or 3)
   int ntiles;           // set by the launcher
   int dbg;              // experiment switches (GAM_SP_DBG), 0 in production
   float wscale_inv;     // 2^-wshift, applied to the accumulator in the epilogue

@@ -55,7 +55,7 @@
 #define GAM_SP_MIN_M 1      // rows from which the encoder runs on this kernel family: all (with split-K for small grids it beats the
                             // 128x128 register-staged kernels from one 5 s clip up, profiles/r03_smallm_sweep.txt); GAM_SP_MIN_M overrides
 
-template <int MT, int NW>
+template <int MT, int NW, int NS = 2>
 struct GamGemmSpCfg {
   static constexpr int BM = 64 * MT;
   static constexpr int BN = 64 * NW;
@@ -64,15 +64,21 @@ struct GamGemmSpCfg {
   static constexpr int A_BYTES = BM * 128;
   static constexpr int W_BYTES = BN * 128;
   static constexpr int STAGE = A_BYTES + W_BYTES;
-  static constexpr int SMEM = 2 * STAGE;
+  static constexpr int SMEM = NS * STAGE;      // NS LDS stages: the k-tiles kt .. kt + NS - 1 are resident / in flight
   static constexpr int NAI = BM / 8 / NWAVES;   // A DMA pieces per wave per k-tile (8 rows x 128 B each)
   static constexpr int NWI = BN / 8 / NWAVES;   // W DMA pieces per wave per k-tile
 };
 
-template <int ACT, int MT, int NW>
+// NS = LDS stages.  2: the k-tile after next lands while the current one is multiplied -- enough for the 8-wave tiles, whose
+// k-tile takes 1.4-1.8 us of MFMA work.  3 (r04, the 4-wave tiles of small grids): a 128 x 128 k-tile is 0.3 us of MFMA work but
+// its 32 KB take ~0.8 us from issue to landed, and with two stages exactly ONE k-tile of fetch is in flight, so the loop ran at
+// the fetch latency (per-workgroup timeline, profiles/r04_gemm_timeline_m2008.txt: 0.78 us per k-tile at M = 2008 whatever the
+// shape).  With three stages TWO k-tiles are in flight: the in-loop wait is a counted vmcnt (the newest tile's pieces may still
+// be outstanding) in front of a bare s_barrier -- __syncthreads() would drain the queue (cdna_hip_programming.md, glds rule).
+template <int ACT, int MT, int NW, int NS = 2>
 __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(GamGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gam_smem_sp[];
-  using Cfg = GamGemmSpCfg<MT, NW>;
+  using Cfg = GamGemmSpCfg<MT, NW, NS>;
   constexpr int BM = Cfg::BM, BN = Cfg::BN, NAI = Cfg::NAI, NWI = Cfg::NWI, NWAVES = Cfg::NWAVES;
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef const __attribute__((address_space(1))) void* glb_ptr_t;
@@ -247,32 +253,47 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
   // static priority for the later-dispatched half of the workgroup's waves (the arbitration loser on every phase:
   // MI355X_MICROARCH.md "Two waves per SIMD", item 4)
   if (g.prio && wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
-  issue(0);
-  issue(1);   // (nk == 1: fetches tile 0 again, unused)
-  __builtin_amdgcn_s_waitcnt(0x0070);
-  __syncthreads();   // both tiles have landed for every wave
+  // in-loop wait: everything but the newest (NS - 2) k-tiles' DMA pieces of this wave has landed (vmcnt counts in issue order)
+  constexpr int VMW = (NS - 2) * NG;
+  static_assert(VMW < 64, "vmcnt field");
+#pragma unroll
+  for (int st_ = 0; st_ < NS; ++st_) issue(st_);   // (fewer k-tiles than stages: the last one is fetched again, unused)
+  if constexpr (NS == 2) {
+    __builtin_amdgcn_s_waitcnt(0x0070);
+    __syncthreads();   // both tiles have landed for every wave
+  } else {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VMW) : "memory");   // tiles 0 and 1 have landed for every wave
+  }
   GAM_SP_TL(1);
 #pragma unroll
   for (int q = 0; q < NR; ++q) GAM_SP_RDITEM(0, q, gam_smem_sp, o_h0, o_l0);
   const int nk_run = (GAM_SP_DBG(g) & 2) ? 1 : nk;
+  int s_cur = 0;       // LDS stage of k-tile kt
   for (int kt = 0; kt < nk_run; ++kt) {
-    const unsigned char* st = gam_smem_sp + (kt & 1) * Cfg::STAGE;
-    const unsigned char* sn = gam_smem_sp + ((kt & 1) ^ 1) * Cfg::STAGE;
+    const int s_nxt = s_cur + 1 == NS ? 0 : s_cur + 1;
+    const unsigned char* st = gam_smem_sp + s_cur * Cfg::STAGE;
+    const unsigned char* sn = gam_smem_sp + s_nxt * Cfg::STAGE;
     long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
     if (GAM_SP_DBG(g) & 4) c0 = clock64();
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): set 0 landed (read >= 2/3 of a phase ago)
     phase(C0_{}, F_{}, st, o_h1, o_l1, 0);
     if (GAM_SP_DBG(g) & 4) c1 = clock64();
-    // vmcnt(0) by hand: this wave's DMA pieces of tile kt+1 have landed (hipcc does not reliably order
-    // an LDS-DMA against the ds_reads behind a later barrier); lgkmcnt(0): set 1 is in registers
-    __builtin_amdgcn_s_waitcnt(0x0070);
-    if (!(GAM_SP_DBG(g) & 8)) __syncthreads();
+    // vmcnt by hand: this wave's DMA pieces of tile kt+1 have landed (hipcc does not order an LDS-DMA against the
+    // ds_reads behind a later barrier); lgkmcnt(0): set 1 is in registers
+    if constexpr (NS == 2) {
+      __builtin_amdgcn_s_waitcnt(0x0070);
+      if (!(GAM_SP_DBG(g) & 8)) __syncthreads();
+    } else {
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(VMW) : "memory");
+    }
     if (GAM_SP_DBG(g) & 4) c2 = clock64();
     // Unconditional (one copy of the MFMA stream; a second, DMA-less copy behind a branch made hipcc
     // double-buffer the accumulators): past the end the set-0 reads fetch stale LDS that is never used
     // and the DMA re-fetches the last k-tile into a stage nobody reads again (drained before the epilogue).
-    phase(C1_{}, T_{}, sn, o_h0, o_l0, kt & 1);
+    // The refill goes to the stage of tile kt: every wave has read its last fragments before the barrier above.
+    phase(C1_{}, T_{}, sn, o_h0, o_l0, s_cur);
     if (GAM_SP_DBG(g) & 4) { c3 = clock64(); t_mm0 += c1 - c0; t_bar += c2 - c1; t_mm1 += c3 - c2; }
+    s_cur = s_nxt;
   }
   if ((GAM_SP_DBG(g) & 4) && lane == 0 && (lid == 0 || lid == (int)gridDim.x - 1)) {
     // [total clk, total wall(100 MHz), phase 0, barrier, phase 1] of one wave
@@ -387,11 +408,12 @@ static inline bool gam_gemm_sp_epilogue_ok(const GamGemmArgs& a) {
          (a.R == nullptr || (a.ldr % 4 == 0 && al16(a.R)));
 }
 
-template <int ACT, int MT, int NW>
+template <int ACT, int MT, int NW, int NS = 2>
 static inline void gam_launch_gemm_sp_t(const GamGemmArgs& a, int grid, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_devs{0};
-  constexpr int smem = GamGemmSpCfg<MT, NW>::SMEM;
-  auto kern = gam_gemm_sp_kernel<ACT, MT, NW>;
+  constexpr int smem = GamGemmSpCfg<MT, NW, NS>::SMEM;
+  static_assert(smem <= 160 * 1024, "LDS stages do not fit a CU");
+  auto kern = gam_gemm_sp_kernel<ACT, MT, NW, NS>;
   if (gam_set_max_lds(reinterpret_cast<const void*>(kern), smem, attr_devs) != hipSuccess) return;
   hipLaunchKernelGGL(kern, dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(128 * NW), smem, stream, a);
 }
@@ -402,8 +424,23 @@ static inline void gam_launch_gemm_sp_t(const GamGemmArgs& a, int grid, hipStrea
 // strong-scaling points, single clips).  The plan minimises a time model fitted to the sweep of tools/smallm_sweep.py
 // (profiles/r03_smallm_sweep.txt): the busiest CU runs ceil(workgroups / slots) workgroups of
 //   nk / S k-tiles x t_kt(MT, NW, sharing) + t_fix(NW, S > 1),    plus, for S > 1, the reduce pass over (S + 1) M N floats.
-struct GamSpPlan { int mt, nw, s; };
-static int g_gam_sp_force[3] = {-1, -1, -1};    // tuning hook (gam_tune_sp / GAM_SP_MT, GAM_SP_NW, GAM_SP_SPLITK): 0 = free
+struct GamSpPlan { int mt, nw, s, ns; };   // tile rows / 64, tile columns / 64, split-K slices, LDS stages
+// tuning hook (gam_tune_sp / GAM_SP_MT, GAM_SP_NW, GAM_SP_SPLITK): 0 = free.  Process-wide by design (a sweep tool's knob), so it
+// is race-free by construction: the environment is read once (thread-safe function-local static), the fields are atomics,
+// and every handle's hipGraph key carries the three values (gam_api.hip), so a plan forced after a shape was captured
+// cannot replay the old tiling.
+struct GamSpForce {
+  std::atomic<int> mt{0}, nw{0}, s{0}, ns{0};
+  GamSpForce() {
+    const char* e0 = getenv("GAM_SP_MT"); const char* e1 = getenv("GAM_SP_NW"); const char* e2 = getenv("GAM_SP_SPLITK");
+    const char* e3 = getenv("GAM_SP_STAGES");
+    mt = e0 ? atoi(e0) : 0; nw = e1 ? atoi(e1) : 0; s = e2 ? atoi(e2) : 0; ns = e3 ? atoi(e3) : 0;
+  }
+};
+// tile classes with a three-stage instantiation: the 4-wave tiles (128-wide) and the 128 x 256 8-wave tile (3 x 48 KB)
+static inline bool gam_sp_has_ns3(int mt, int nw) { return (nw == 2 && (mt == 2 || mt == 3)) || (nw == 4 && mt == 2); }
+static inline GamSpForce& gam_sp_force() { static GamSpForce f; return f; }
+static inline int gam_env_int_once(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
 static inline double gam_gemm_sp_model(int M, int N, int K, int a_mode, int t, int w, int S, int ncu) {
   // least-squares fit (log error) to the 810 points of profiles/r03_smallm_sweep.txt -- five layer shapes x six row counts x
   // every (MT, NW, S) -- r.m.s. 10 %, the planned configuration within 1 % of the best measured one on average (worst 11 %)
@@ -426,12 +463,10 @@ static inline double gam_gemm_sp_model(int M, int N, int K, int a_mode, int t, i
   return us;
 }
 static inline GamSpPlan gam_gemm_sp_plan(int M, int N, int K, int a_mode = 0, int ncu = 256) {
-  if (g_gam_sp_force[0] < 0) {
-    const char* e0 = getenv("GAM_SP_MT"); const char* e1 = getenv("GAM_SP_NW"); const char* e2 = getenv("GAM_SP_SPLITK");
-    g_gam_sp_force[0] = e0 ? atoi(e0) : 0; g_gam_sp_force[1] = e1 ? atoi(e1) : 0; g_gam_sp_force[2] = e2 ? atoi(e2) : 0;
-  }
-  const int f_mt = g_gam_sp_force[0], f_nw = g_gam_sp_force[1], f_s = g_gam_sp_force[2];
-  GamSpPlan best = {3, 4, 1};
+  GamSpForce& frc = gam_sp_force();
+  const int f_mt = frc.mt.load(std::memory_order_relaxed), f_nw = frc.nw.load(std::memory_order_relaxed), f_s = frc.s.load(std::memory_order_relaxed);
+  const int f_ns = frc.ns.load(std::memory_order_relaxed);
+  GamSpPlan best = {3, 4, 1, 2};
   double bt = 1e30;
   const int nk = K / 32;
   for (int w = 4; w >= 2; w -= 2) {
@@ -443,10 +478,11 @@ static inline GamSpPlan gam_gemm_sp_plan(int M, int N, int K, int a_mode = 0, in
         if (S > 1 && (nk % S != 0 || nk / S < 4)) continue;     // whole k-tiles, and enough of them to fill the two-stage pipeline
         if (f_s < 1 && S > 1 && (long)gam_cdiv(M, 64 * t) * gam_cdiv(N, 64 * w) * 2 > ncu) continue;   // only for grids under half the chip
         const double us = gam_gemm_sp_model(M, N, K, a_mode, t, w, S, ncu);
-        if (us < bt - 1e-9) { bt = us; best = {t, w, S}; }
+        if (us < bt - 1e-9) { bt = us; best = {t, w, S, 2}; }
       }
     }
   }
+  if (f_ns == 3 && gam_sp_has_ns3(best.mt, best.nw)) best.ns = 3;
   return best;
 }
 
@@ -457,20 +493,19 @@ static inline hipError_t gam_launch_gemm_sp(const GamGemmArgs& a_in, int act, hi
   if (a.a_mode == 0 ? (a.lda % 32 != 0) : (a.conv_c % 32 != 0)) return hipErrorInvalidValue;
   if (!gam_gemm_sp_epilogue_ok(a)) return hipErrorInvalidValue;
   // the caller made the plan (it owns the split-K workspace): a.sp_mt / a.sp_nw / a.splitk (+ a.partial when > 1)
-  int mt = a.sp_mt, nw = a.sp_nw;
+  int mt = a.sp_mt, nw = a.sp_nw, ns = a.sp_ns;
   if (mt < 2 || mt > 4 || (nw != 2 && nw != 4) || (nw == 2 && mt == 4)) {
     const GamSpPlan p = gam_gemm_sp_plan(a.M, a.N, a.K, a.a_mode);
-    mt = p.mt; nw = p.nw;
+    mt = p.mt; nw = p.nw; ns = p.ns;
     if (a.splitk > 1 && a.partial == nullptr) return hipErrorInvalidValue;
   }
+  if (ns != 3 || !gam_sp_has_ns3(mt, nw)) ns = 2;
   if (a.splitk > 1 && (a.partial == nullptr || (a.K / 32) % a.splitk != 0)) return hipErrorInvalidValue;
   if (a.n_switch > 0 && (a.Asp2 == nullptr || a.a_mode != 0 || a.n_switch % (64 * nw) != 0)) return hipErrorInvalidValue;
   if (a.splitk <= 1) { a.splitk = 0; a.partial = nullptr; }
   const int grid = gam_cdiv(a.M, 64 * mt) * gam_cdiv(a.N, 64 * nw);
   a.ntiles = grid;
-  static int dbg = -1, prio = -1;
-  if (dbg < 0) { const char* e = getenv("GAM_SP_DBG"); dbg = e ? atoi(e) : 0; }
-  if (prio < 0) { const char* e = getenv("GAM_SP_PRIO"); prio = e ? atoi(e) : 0; }
+  static const int dbg = gam_env_int_once("GAM_SP_DBG"), prio = gam_env_int_once("GAM_SP_PRIO");   // (thread-safe one-time init)
   a.dbg = dbg;
   a.prio = prio;
 #if GAM_SP_INSTRUMENT
@@ -483,7 +518,11 @@ static inline hipError_t gam_launch_gemm_sp(const GamGemmArgs& a_in, int act, hi
   }
 #endif
 #define GAM_LSP(ACTV)                                                            \
-  if (nw == 2) switch (mt) {                                                     \
+  if (ns == 3) {                                                                 \
+    if (nw == 4) gam_launch_gemm_sp_t<ACTV, 2, 4, 3>(a, grid, stream);           \
+    else if (mt == 2) gam_launch_gemm_sp_t<ACTV, 2, 2, 3>(a, grid, stream);      \
+    else gam_launch_gemm_sp_t<ACTV, 3, 2, 3>(a, grid, stream);                   \
+  } else if (nw == 2) switch (mt) {                                              \
     case 2: gam_launch_gemm_sp_t<ACTV, 2, 2>(a, grid, stream); break;            \
     default: gam_launch_gemm_sp_t<ACTV, 3, 2>(a, grid, stream); break;           \
   } else switch (mt) {                                                           \

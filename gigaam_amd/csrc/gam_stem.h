@@ -77,8 +77,9 @@ __global__ __launch_bounds__(256) void gam_conv2d1_kernel(GamConv1Args a) {
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) acc = fmaf(w[kh * 3 + kw], xin[kh][fb + kw], acc);
-      if (a.img_split) gam_range_note(a.range_flag, acc, 0.f, 0.f, 0.f);   // the image feeds Conv2d#2 unscaled
-      gam_store1(out, (size_t)q * a.C, c, fmaxf(acc, 0.f), a.img_split);
+      acc = fmaxf(acc, 0.f);
+      if (a.img_split) gam_range_note(a.range_flag, acc, 0.f, 0.f, 0.f);   // the stored (post-ReLU) image feeds Conv2d#2 unscaled
+      gam_store1(out, (size_t)q * a.C, c, acc, a.img_split);
     }
   }
 }

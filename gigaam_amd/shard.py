@@ -41,6 +41,29 @@ def deal(n_batches: int, rank: int, n_ranks: int, snake: bool = True) -> List[in
     return out
 
 
+def lpt_deal(costs: Sequence[float], n_ranks: int) -> List[List[int]]:
+    """Longest-processing-time-first dealing of ITEMS (not batches): items in order of falling cost (ties: lower index
+    first), each to the rank with the smallest total so far (ties: lower rank).  Returns, per rank, its items in the order
+    they were dealt, i.e. sorted by falling cost.  The classic 4/3-approximation of the balanced partition; with many
+    items per rank the totals agree to within one small item."""
+    order = sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i))
+    load = [0.0] * n_ranks
+    out: List[List[int]] = [[] for _ in range(n_ranks)]
+    for i in order:
+        r = min(range(n_ranks), key=lambda q: (load[q], q))
+        out[r].append(i)
+        load[r] += float(costs[i])
+    return out
+
+
+def rank_batches(costs: Sequence[float], n_ranks: int, batch_size: int) -> List[List[List[int]]]:
+    """Per rank, its ``lpt_deal`` share cut into consecutive batches of ``batch_size``: every rank gets the same amount of
+    audio (not the same number of batches), and every batch holds chunks of neighbouring lengths (its padding is bounded
+    by the length spread inside it).  Config 5 / longform sharding: the reference's loop (gigaam/model.py:219-258) batches
+    in file order on one device; here the FILE ORDER is restored in the returned result only (unpack_results)."""
+    return [[share[k:k + batch_size] for k in range(0, len(share), batch_size)] for share in lpt_deal(costs, n_ranks)]
+
+
 def pack_results(rows: Sequence[Tuple[int, Sequence[int], Sequence[int]]], n_rows: int, cap: int):
     """Local decode results [(global_index, ids, frames)] -> fixed-shape buffers for the gather:
     index i32 [n_rows] (-1 = unused row), counts i32 [n_rows], ids / frames i32 [n_rows, cap]."""
@@ -76,6 +99,46 @@ def unpack_results(index: Tensor, counts: Tensor, ids: Tensor, frames: Tensor, n
     if missing:
         raise RuntimeError(f"{len(missing)} utterances were never decoded (first: {missing[:5]})")
     return out
+
+
+# --------------------------------------------------------------------------- the range flag across the exchange
+# One rank's split-fp16 range flag (engine.HipEngine: it arrives in the hidden tail word of the decode's counts buffer)
+# must survive padding, the gather and the row selection.  It travels as ONE extra row of the exchanged buffers whose
+# index word is FLAG_CLEAR or FLAG_SET (both negative: never mistaken for an utterance), so every rank learns every
+# rank's flag in the exchange it performs anyway -- no extra host synchronisation, no attribute on a tensor view.
+FLAG_CLEAR, FLAG_SET = -1, -2
+
+
+def range_flag_of(counts: Tensor) -> Optional[Tensor]:
+    """The device word that received the range flag of the decode that produced ``counts`` (i32 [1]), or None."""
+    ext = getattr(counts, "_gam_ext", None)
+    return None if ext is None else ext[-1:]
+
+
+def append_flag_row(index: Tensor, counts: Tensor, ids: Tensor, frames: Tensor, flag: Optional[Tensor], rows: int):
+    """Pad the local buffers to ``rows`` rows (index -1) and append the flag row: rows + 1 rows in all."""
+    n, dev = ids.shape[0], ids.device
+    assert n <= rows and index.shape[0] == rows
+    pad = rows + 1 - n
+    fi = torch.full((1,), FLAG_CLEAR, dtype=index.dtype, device=dev) if flag is None else (FLAG_CLEAR - (flag != 0).to(index.dtype)).reshape(1).to(dev)
+    return (torch.cat([index, fi]), torch.cat([counts, counts.new_zeros((pad,))]),
+            torch.cat([ids, ids.new_zeros((pad, ids.shape[1]))]), torch.cat([frames, frames.new_zeros((pad, frames.shape[1]))]))
+
+
+def collect_gathered(gi: Tensor, gc: Tensor, gids: Tensor, gfr: Tensor):
+    """Gathered buffers (rank-major, flag rows included) -> ([(ids, frames)] of the rows with index >= 0 in gathered
+    order, their global indices, any_flag).  Two blocking copies: (index, counts), then the used part of ids / frames."""
+    head = torch.stack([gi.to(torch.int32), gc.to(torch.int32)]).cpu()
+    gi_h, gc_h = head[0].tolist(), head[1].tolist()
+    flag = any(g == FLAG_SET for g in gi_h)
+    sel = [r for r, g in enumerate(gi_h) if g >= 0]
+    width = max((gc_h[r] for r in sel), default=0)
+    if not sel:
+        return [], [], flag
+    st = torch.tensor(sel, dtype=torch.long, device=gids.device)
+    both = torch.stack([gids.index_select(0, st)[:, :width], gfr.index_select(0, st)[:, :width]]).cpu()
+    rows = [(both[0, k, :gc_h[r]].tolist(), both[1, k, :gc_h[r]].tolist()) for k, r in enumerate(sel)]
+    return rows, [gi_h[r] for r in sel], flag
 
 
 def run_sharded(batches: Sequence[Tuple[Tensor, Tensor, Sequence[int]]], decode_batch: Callable, rank: int, n_ranks: int,

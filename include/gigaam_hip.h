@@ -157,6 +157,12 @@ int gam_tune_sp(int mt, int nw, int splitk);
 /* The plan a launch of C[M,N] = A[M,K].W[N,K]^T would get on a device with n_cu compute units (host-side only: no GPU
  * needed; K % 32 == 0): tile rows = 64 * mt, tile columns = 64 * nw, split-K slices. */
 int gam_plan_sp(int M, int N, int K, int n_cu, int* mt, int* nw, int* splitk);
+/* The same with the fourth plan dimension (r04): the number of LDS stages of the kernel's operand pipeline -- 2 (the k-tile
+ * after next lands while the current one is multiplied) or 3 (two k-tiles in flight: the 4-wave tiles of small grids, whose
+ * k-tile is shorter than its fetch latency).  gam_tune_sp_stages forces it (0 = planned, 2, 3); tiles without a three-stage
+ * build keep 2. */
+int gam_plan_sp_ex(int M, int N, int K, int n_cu, int* mt, int* nw, int* splitk, int* stages);
+int gam_tune_sp_stages(int stages);
 
 /* Per-kernel-class HIP-event timing on the launch stream (bench.py's roofline leg).
  * gam_profile_enable(h,1) starts collecting for every launch, (h,2) for the GEMM family only

@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
-"""Experiment: the 32 x 20 s batch as TWO independent half-batches on two HIP streams (two library handles), so that
-one half's GEMM prologues / epilogues / LayerNorms / attention overlap the other half's MFMA main loops.
-Prints ms per 32-utterance step for 1 stream x 32 and 2 streams x 16 (and 4 x 8)."""
+"""Experiment: one batch of B x 20 s as P independent part-batches on P HIP streams (P library handles), so that one
+part's GEMM prologues / epilogues / LayerNorms / attention overlap the other parts' MFMA main loops.
+
+    python tools/exp_two_streams.py [--batch 32] [--parts 1,2,4,1,2] [--reps 10]
+
+Prints ms per B-utterance step for every P.  r02 (B = 32, power-capped): no gain.  r04 asks the same question at the
+strong-scaling points (B = 4 / 8), where the step is latency-bound rather than power-bound."""
+import argparse
 import os
 import sys
 import time
@@ -15,14 +20,22 @@ from gigaam_amd import synth, workloads  # noqa: E402
 
 
 def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--parts", default="1,2,4,1,2")
+    ap.add_argument("--reps", type=int, default=10)
+    args = ap.parse_args()
     dev = torch.device("cuda:0")
     ck = synth.make_checkpoint("v2_ctc", seed=0)
-    wav, wlen = workloads.config2_batch(32, 20.0)
+    B = args.batch
+    wav, wlen = workloads.config2_batch(B, 20.0)
     wav, wlen = wav.to(dev), wlen.to(dev)
-    for parts in (1, 2, 4, 1, 2):
+    for parts in [int(p) for p in args.parts.split(",")]:
+        if B % parts:
+            continue
         engs = [gigaam_amd.model_from_checkpoint(ck, dev).encoder.engine for _ in range(parts)]
         streams = [torch.cuda.Stream(dev) for _ in range(parts)]
-        n = 32 // parts
+        n = B // parts
         chunks = [(wav[i * n:(i + 1) * n].contiguous(), wlen[i * n:(i + 1) * n].contiguous()) for i in range(parts)]
 
         def step():
@@ -33,16 +46,15 @@ def main():
                     outs.append(e.ctc_greedy(enc, elen))
             return outs
 
-        for _ in range(3):
+        for _ in range(4):
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        k = 10
-        for _ in range(k):
+        for _ in range(args.reps):
             step()
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / k * 1e3
-        print(f"{parts} stream(s) x {n} utterances: {ms:.2f} ms per 32 x 20 s ({640.0 / ms * 1e3:.0f} x real time)", flush=True)
+        ms = (time.perf_counter() - t0) / args.reps * 1e3
+        print(f"{parts} stream(s) x {n} utterances: {ms:.3f} ms per {B} x 20 s ({B * 20.0 / ms * 1e3:.0f} x real time)", flush=True)
         del engs
 
 

@@ -25,6 +25,8 @@ def main():
               (16064, 1536, 768, 0), (16064, 768, 12288, 0), (4016, 768, 768, 0), (2500, 700, 96, 2)]
     if len(sys.argv) > 1 and sys.argv[1] == "quick":
         shapes = shapes[:3]
+    elif len(sys.argv) > 1:      # "M,N,K,act;M,N,K,act;..."
+        shapes = [tuple(int(v) for v in t.split(",")) for t in sys.argv[1].split(";") if t]
     engs = [("base", engine(0)), ("sp", engine(1))]
     if os.environ.get("GAM_SP_DBG"):
         engs = engs[1:]

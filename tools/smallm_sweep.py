@@ -38,12 +38,15 @@ def timed(e, a, w, b, act, reps=10):
 
 def main():
     calib = "--calib" in sys.argv
+    stages = "--stages" in sys.argv       # r04: every configuration also with three LDS stages where the tile has that build
+    rows_arg = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--rows=")), None)
+    m_list = [int(v) for v in rows_arg.split(",")] if rows_arg else [126, 1004, 2008, 4016, 8032, 16064]
     base, sp = engine(1 << 30), engine(1)
     lib = sp.lib
     torch.manual_seed(0)
     rows = []
-    for m in (126, 1004, 2008, 4016, 8032, 16064):
-        for (n, k, act) in ((3072, 768, 1), (768, 3072, 0), (1536, 768, 0), (768, 768, 0), (768, 12288, 0)):
+    for m in m_list:
+        for (n, k, act) in ((3072, 768, 1), (768, 3072, 0), (1536, 768, 0), (768, 768, 0), (2304, 768, 0), (768, 12288, 0)):
             a = torch.randn(m, k, device="cuda")
             w = torch.randn(n, k, device="cuda") / k ** 0.5
             b = torch.randn(n, device="cuda")
@@ -51,6 +54,7 @@ def main():
             if act == 1:
                 ref = ref * torch.sigmoid(ref)
             lib.gam_tune_sp(0, 0, 0)
+            lib.gam_tune_sp_stages(0)
             err = float((sp.op_gemm(a, w, b, act).double() - ref).abs().max() / ref.abs().max())
             rec = {"M": m, "N": n, "K": k, "base": timed(base, a, w, b, act), "sp": timed(sp, a, w, b, act), "rel_err": err}
             line = (f"M={m:5d} N={n:5d} K={k:6d} act={act}  ideal@360TF {2.0*m*n*k/360e6:6.1f} us | base {rec['base']:7.1f} | "
@@ -63,13 +67,19 @@ def main():
                         if s_ > 1 and (nk % s_ or nk // s_ < 4):
                             continue
                         lib.gam_tune_sp(mt, nw, s_)
-                        out = sp.op_gemm(a, w, b, act)
-                        e2 = float((out.double() - ref).abs().max() / ref.abs().max())
-                        assert e2 < 3e-5, (m, n, k, mt, nw, s_, e2)
-                        allc[f"{mt}x{nw}/S{s_}"] = round(timed(sp, a, w, b, act, reps=6), 1)
+                        has3 = (nw == 2 and mt in (2, 3)) or (nw == 4 and mt == 2)
+                        for ns in ((2, 3) if (stages and has3) else (2,)):
+                            if ns == 3 and s_ > 1 and nk // s_ < 4:
+                                continue
+                            lib.gam_tune_sp_stages(ns)
+                            out = sp.op_gemm(a, w, b, act)
+                            e2 = float((out.double() - ref).abs().max() / ref.abs().max())
+                            assert e2 < 3e-5, (m, n, k, mt, nw, s_, ns, e2)
+                            allc[f"{mt}x{nw}/S{s_}" + ("/n3" if ns == 3 else "")] = round(timed(sp, a, w, b, act, reps=6), 1)
                 lib.gam_tune_sp(0, 0, 0)
+                lib.gam_tune_sp_stages(0)
                 rec["configs"] = allc
-                top = sorted(allc.items(), key=lambda kv: kv[1])[:4]
+                top = sorted(allc.items(), key=lambda kv: kv[1])[:8]
                 line += " | best: " + ", ".join(f"{c} {t}" for c, t in top)
             rows.append(rec)
             print(line, flush=True)
