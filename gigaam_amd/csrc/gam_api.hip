@@ -1255,10 +1255,10 @@ int gam_ctc_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len, 
   hipStream_t s = (hipStream_t)stream;
   if (int r = ctc_logits(h, encoded, B, Tp, s)) return r;
   const int V = h->cfg.num_classes;
-  const size_t sm = ((size_t)Tp + 8) * sizeof(int);
+  const size_t sm = ((size_t)Tp + GAM_CTC_NT / 64 + 8) * sizeof(int);
   if (sm > 60 * 1024) return fail(h, -1, "T'=%lld too long for the CTC greedy kernel", (long long)Tp);
   ProfScope ps(h, s, GAM_PF_DECODE, (double)B * Tp * V * 4.0);
-  hipLaunchKernelGGL(gam_ctc_greedy_kernel, dim3(B), dim3(256), sm, s, h->logits.p, enc_len, (int)Tp, V, ids, frames, counts);
+  hipLaunchKernelGGL(gam_ctc_greedy_kernel, dim3(B), dim3(GAM_CTC_NT), sm, s, h->logits.p, enc_len, (int)Tp, V, ids, frames, counts);
   HIPCHK(h, hipGetLastError());
   return 0;
 }

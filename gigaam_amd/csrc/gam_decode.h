@@ -23,12 +23,18 @@ __global__ __launch_bounds__(256) void gam_log_softmax_kernel(const float* x, fl
 }
 
 // ------------------------------------------------------------------ CTC greedy
-// one workgroup per utterance.  Phase 1: one wave per frame, argmax with torch's
-// first-max tie rule -> labels in LDS.  Phase 2: keep = label != blank && (t == 0 ||
-// label != label[t-1]) && t < len; ballot/popcount prefix compaction.
-__global__ __launch_bounds__(256) void gam_ctc_greedy_kernel(const float* logits, const int* enc_len, int Tp, int V,
-                                                             int* ids, int* frames, int* counts) {
-  extern __shared__ int gam_smem_ctc[];   // labels[Tp] + wave totals[4] + base[1]
+// one workgroup (GAM_CTC_NT threads) per utterance.  Phase 1: argmax with torch's first-max tie rule -> labels in LDS.
+// Phase 2: keep = label != blank && (t == 0 || label != label[t-1]) && t < len; ballot/popcount prefix compaction.
+// Phase 1 has two forms.  Character vocabularies (V <= 64, the published CTC models: V = 34): ONE THREAD PER FRAME -- a
+// frame's V logits are V/2 eight-byte loads of one lane, all of them in flight before the first compare, the scan is a
+// register loop with no cross-lane traffic, and 501 frames are one pass of the 512 threads: a single L2 round trip instead
+// of the 16 dependent ones of the wave-per-frame form (r03: 71 us at every batch size -- 2.3 % of a single clip's step).
+// Larger vocabularies (V = 257 / 1025): one wave per frame, lanes stride the classes.
+#define GAM_CTC_NT 512
+__global__ __launch_bounds__(GAM_CTC_NT) void gam_ctc_greedy_kernel(const float* logits, const int* enc_len, int Tp, int V,
+                                                                    int* ids, int* frames, int* counts) {
+  extern __shared__ int gam_smem_ctc[];   // labels[Tp] + wave totals[NT / 64]
+  constexpr int NWV = GAM_CTC_NT / 64;
   int* lab = gam_smem_ctc;
   int* wtot = gam_smem_ctc + Tp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -36,33 +42,26 @@ __global__ __launch_bounds__(256) void gam_ctc_greedy_kernel(const float* logits
   const int blank = V - 1;
   int len = enc_len[b];
   len = len < 0 ? 0 : (len > Tp ? Tp : len);   // decoding.py:76 clamp
-  if (V <= 64) {
-    // character vocabularies (V = 34): a frame's logits are ONE load per lane, and the loop is a chain of dependent L2 round
-    // trips (32 utterances = 32 workgroups: nothing else hides them) -- eight frames per wave are in flight at once
-    // (108 -> ~25 us for 501 frames)
-    constexpr int FRU = 8;
-    for (int t0 = wave * FRU; t0 < Tp; t0 += 4 * FRU) {
-      float x[FRU];
+  if (V <= 64 && (V & 1) == 0) {
+    const int hv = V >> 1;
+    for (int t = tid; t < Tp; t += GAM_CTC_NT) {
+      const float2* xr = reinterpret_cast<const float2*>(logits + ((size_t)b * Tp + t) * V);   // (V even: 8-byte aligned rows)
+      float2 x[32];
 #pragma unroll
-      for (int u = 0; u < FRU; ++u) {
-        const int tt = t0 + u < Tp ? t0 + u : Tp - 1;
-        x[u] = logits[((size_t)b * Tp + tt) * V + (lane < V ? lane : V - 1)];
-      }
+      for (int j = 0; j < 32; ++j) x[j] = xr[j < hv ? j : 0];
+      float best = -INFINITY;
+      int bi = 0x7fffffff;
 #pragma unroll
-      for (int u = 0; u < FRU; ++u) {
-        float best = lane < V ? x[u] : -INFINITY;
-        int bi = lane < V ? lane : 0x7fffffff;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-          const float ob = __shfl_xor(best, o, 64);
-          const int oi = __shfl_xor(bi, o, 64);
-          if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+      for (int j = 0; j < 32; ++j) {
+        if (j < hv) {    // ascending class order + strict '>' = first maximum
+          if (x[j].x > best || bi == 0x7fffffff) { best = x[j].x; bi = 2 * j; }
+          if (x[j].y > best) { best = x[j].y; bi = 2 * j + 1; }
         }
-        if (lane == 0 && t0 + u < Tp) lab[t0 + u] = bi;
       }
+      lab[t] = bi;
     }
   } else {
-    for (int t = wave; t < Tp; t += 4) {
+    for (int t = wave; t < Tp; t += NWV) {
       const float* xr = logits + ((size_t)b * Tp + t) * V;
       float best = -INFINITY;
       int bi = 0x7fffffff;
@@ -81,7 +80,7 @@ __global__ __launch_bounds__(256) void gam_ctc_greedy_kernel(const float* logits
   }
   __syncthreads();
   int base = 0;
-  for (int t0 = 0; t0 < Tp; t0 += 256) {
+  for (int t0 = 0; t0 < Tp; t0 += GAM_CTC_NT) {
     const int t = t0 + tid;
     bool keep = false;
     int l = 0;
@@ -93,9 +92,13 @@ __global__ __launch_bounds__(256) void gam_ctc_greedy_kernel(const float* logits
     const int before = __popcll(m & ((1ull << lane) - 1ull));
     if (lane == 0) wtot[wave] = __popcll(m);
     __syncthreads();
-    int woff = 0;
-    for (int w = 0; w < wave; ++w) woff += wtot[w];
-    const int tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+      const int c = wtot[w];
+      woff += w < wave ? c : 0;
+      tot += c;
+    }
     if (keep) {
       const int pos = base + woff + before;
       ids[(size_t)b * Tp + pos] = l;

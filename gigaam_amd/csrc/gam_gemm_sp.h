@@ -320,6 +320,9 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
   //      the former per-wave LDS round trip (96 ds_write_b32 + 24 ds_read_b128 per wave, 8 waves on one LDS) cost
   //      5.0 of the 7.3 us a 192 x 256 tile spent here (profiles/r03_gemm_timeline.txt); lanes l and l + 32 write
   //      adjacent 16-byte pieces of a row, the four quads complete its 128-byte line.
+  // (r04, tried and dropped: requesting the bias pieces and the row scales of the 4-wave tiles in front of the first k-tile, so
+  //  that the epilogue of a small-grid launch does not start with an L2 round trip -- 32 + MT more live registers, same-box A/B
+  //  6.22-6.24 vs 6.24-6.25 ms at 4 x 20 s, 2.85 vs 2.89 ms for one clip: nothing; profiles/r04_ab_experiments.txt)
   const int lrow = lane & 31, lq = (lane >> 5) * 4;
   const float accscale = g.wscale_inv;
   f32x4 bv[2][4];
@@ -441,13 +444,20 @@ struct GamSpForce {
 static inline bool gam_sp_has_ns3(int mt, int nw) { return (nw == 2 && (mt == 2 || mt == 3)) || (nw == 4 && mt == 2); }
 static inline GamSpForce& gam_sp_force() { static GamSpForce f; return f; }
 static inline int gam_env_int_once(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
-static inline double gam_gemm_sp_model(int M, int N, int K, int a_mode, int t, int w, int S, int ncu) {
+static inline double gam_gemm_sp_model(int M, int N, int K, int a_mode, int t, int w, int S, int ncu, int ns = 2) {
   // least-squares fit (log error) to the 810 points of profiles/r03_smallm_sweep.txt -- five layer shapes x six row counts x
-  // every (MT, NW, S) -- r.m.s. 10 %, the planned configuration within 1 % of the best measured one on average (worst 11 %)
+  // every (MT, NW, S) -- r.m.s. 10 %, the planned configuration within 1 % of the best measured one on average (worst 11 %).
+  // r04: the three-stage classes (ns = 3: one workgroup per CU whatever the tile, their LDS image is 96-144 KB) fitted to the
+  // 1370-point sweep of profiles/r04_smallm_sweep_stages.txt (tools/fit_sp_model.py): r.m.s. 8 %, mean regret of the plan over
+  // the 30 shapes 1.7 % (worst 12 %: M = 8032, N = 2304).
   const long wgs = (long)gam_cdiv(M, 64 * t) * gam_cdiv(N, 64 * w) * S;
   const int nkt = K / 32 / S;
   double t_kt, t_fix, rounds;
-  if (w == 4) {
+  if (ns == 3) {
+    if (w == 4) { t_kt = 0.953; t_fix = S > 1 ? 6.62 : 12.8; }                 // 128 x 256, 8 waves
+    else { t_kt = 0.229 * t + 0.115; t_fix = S > 1 ? 4.76 : 12.0; }            // (64 t) x 128, 4 waves
+    rounds = (double)((wgs + ncu - 1) / ncu);
+  } else if (w == 4) {
     t_kt = 0.335 * t + 0.425;                     // us per k-tile, one 8-wave workgroup per CU
     t_fix = S > 1 ? 6.2 : 13.2;                   // launch + prologue + epilogue (partial sums: no bias / residual / split)
     rounds = (double)((wgs + ncu - 1) / ncu);
@@ -475,14 +485,17 @@ static inline GamSpPlan gam_gemm_sp_plan(int M, int N, int K, int a_mode = 0, in
       if (f_mt >= 2 && f_mt <= 4 && t != f_mt && !(w == 2 && f_mt == 4)) continue;
       for (int S = 1; S <= 8; ++S) {
         if (f_s >= 1 && S != f_s) continue;
-        if (S > 1 && (nk % S != 0 || nk / S < 4)) continue;     // whole k-tiles, and enough of them to fill the two-stage pipeline
+        if (S > 1 && (nk % S != 0 || nk / S < 4)) continue;     // whole k-tiles, and enough of them to fill the pipeline
         if (f_s < 1 && S > 1 && (long)gam_cdiv(M, 64 * t) * gam_cdiv(N, 64 * w) * 2 > ncu) continue;   // only for grids under half the chip
-        const double us = gam_gemm_sp_model(M, N, K, a_mode, t, w, S, ncu);
-        if (us < bt - 1e-9) { bt = us; best = {t, w, S, 2}; }
+        for (int ns = 2; ns <= 3; ++ns) {
+          if (ns == 3 && (!gam_sp_has_ns3(t, w) || a_mode != 0)) continue;   // (the implicit-GEMM conv runs the big two-stage tiles)
+          if ((f_ns == 2 || f_ns == 3) && ns != f_ns && !(f_ns == 3 && !gam_sp_has_ns3(t, w))) continue;
+          const double us = gam_gemm_sp_model(M, N, K, a_mode, t, w, S, ncu, ns);
+          if (us < bt - 1e-9) { bt = us; best = {t, w, S, ns}; }
+        }
       }
     }
   }
-  if (f_ns == 3 && gam_sp_has_ns3(best.mt, best.nw)) best.ns = 3;
   return best;
 }
 

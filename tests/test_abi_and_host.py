@@ -287,3 +287,24 @@ def test_gemm_plan_invariants():
     # a partition with fewer CUs shifts the trade
     assert plan(4016, 768, 768, ncu=64)[2] == 1
     assert lib.gam_plan_sp(100, 100, 100, 256, C.byref(C.c_int()), C.byref(C.c_int()), C.byref(C.c_int())) != 0   # K % 32
+
+    # r04: the fourth plan dimension -- LDS stages (profiles/r04_smallm_sweep_stages.txt).  Three stages exist for the
+    # 4-wave tiles and the 128 x 256 tile only; the headline batch keeps the big two-stage tiles; forcing works both ways.
+    def plan_ex(m, n, k):
+        mt, nw, s, ns = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        assert lib.gam_plan_sp_ex(m, n, k, 256, C.byref(mt), C.byref(nw), C.byref(s), C.byref(ns)) == 0
+        return mt.value, nw.value, s.value, ns.value
+
+    assert lib.gam_tune_sp_stages(0) == 0
+    for m in (5, 126, 1004, 2008, 4016, 8032, 16064):
+        for n, k in ((768, 768), (1536, 768), (2304, 768), (3072, 768), (768, 3072)):
+            mt, nw, s, ns = plan_ex(m, n, k)
+            assert (mt, nw, s) == plan(m, n, k) and ns in (2, 3)
+            if ns == 3:
+                assert (nw == 2 and mt in (2, 3)) or (nw == 4 and mt == 2), (m, n, k, mt, nw)
+    assert all(plan_ex(16064, n, k)[3] == 2 for n, k in ((768, 768), (3072, 768), (768, 3072), (2304, 768)))
+    assert plan_ex(2008, 768, 768) == (2, 2, 2, 3) and plan_ex(126, 768, 768)[3] == 3      # the small grids: two k-tiles in flight
+    assert lib.gam_tune_sp_stages(2) == 0 and plan_ex(2008, 768, 768)[3] == 2
+    assert lib.gam_tune_sp_stages(3) == 0 and plan_ex(2008, 768, 768)[3] == 3
+    assert lib.gam_tune_sp_stages(4) != 0
+    assert lib.gam_tune_sp_stages(0) == 0

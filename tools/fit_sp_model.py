@@ -9,6 +9,9 @@ Model (us): rounds x (k-tiles-per-slice x t_kt + t_fix) [+ reduce pass when S > 
   (a third class -- 128 wide with EIGHT waves, a wave owning 32 mt x 32 -- was built and measured in r03: within 1 % of the
    4-wave class at equal tile shape, 4 % better only at 126 rows; dropped.  Configurations named "MTx3" in a sweep file are ignored.)
   reduce: R0 + (S + 2) M N 4 B / RBW
+  r04, configurations named ".../n3" (three LDS stages; always one workgroup per CU):
+  nw 2: t_kt = A23 mt + B23, t_fix = F23 | F23S;   nw 4 (mt = 2 only): t_kt = T43, t_fix = F43 | F43S
+  -- fitted AFTER and separately from the two-stage constants (which stay as fitted in r03 unless --refit2 is given)
 Random-restart coordinate search on the mean squared log error; prints the #defines and the plan's regret (time of the
 configuration the fitted model picks / best measured) per shape."""
 import json
@@ -18,20 +21,34 @@ import random
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = ["A4", "B4", "F4", "F4S", "A2", "B2", "F2", "F2S", "SH2", "SHF2", "R0", "RBW"]
-INIT = [0.335, 0.425, 13.2, 6.2, 0.256, 0.142, 14.1, 4.9, 1.82, 0.73, 7.1, 3.87]
+NAMES = ["A4", "B4", "F4", "F4S", "A2", "B2", "F2", "F2S", "SH2", "SHF2", "R0", "RBW", "A23", "B23", "F23", "F23S", "T43", "F43", "F43S"]
+INIT = [0.335, 0.425, 13.2, 6.2, 0.256, 0.142, 14.1, 4.9, 1.82, 0.73, 7.1, 3.87, 0.2, 0.12, 14.1, 4.9, 0.95, 13.2, 6.2]
+N2 = 12    # the first N2 constants belong to the two-stage classes
 
 
 def cdiv(a, b):
     return (a + b - 1) // b
 
 
-def model(p, M, N, K, t, w, S, ncu=256):
+def parse(c):
+    """'3x2/S4' or '2x2/S1/n3' -> (mt, nw, S, stages)"""
+    parts = c.split("/")
+    mt, nw = parts[0].split("x")
+    return int(mt), int(nw), int(parts[1][1:]), (3 if len(parts) > 2 and parts[2] == "n3" else 2)
+
+
+def model(p, M, N, K, t, w, S, ns=2, ncu=256):
     P = dict(zip(NAMES, p))
     bn = 256 if w == 4 else 128
     wgs = cdiv(M, 64 * t) * cdiv(N, bn) * S
     nkt = K // 32 // S
-    if w == 4:
+    if ns == 3:
+        if w == 4:
+            tk, tf = P["T43"], (P["F43S"] if S > 1 else P["F43"])
+        else:
+            tk, tf = P["A23"] * t + P["B23"], (P["F23S"] if S > 1 else P["F23"])
+        rounds = cdiv(wgs, ncu)
+    elif w == 4:
         tk, tf, rounds = P["A4"] * t + P["B4"], (P["F4S"] if S > 1 else P["F4"]), cdiv(wgs, ncu)
     else:
         c = "2"
@@ -51,24 +68,33 @@ def main():
     data = []
     for r in rows:
         for c, t in r.get("configs", {}).items():
-            mt, rest = c.split("x")
-            nw, s = rest.split("/S")
-            if int(nw) in (2, 4):
-                data.append((r["M"], r["N"], r["K"], int(mt), int(nw), int(s), t))
+            mt, nw, s_, ns = parse(c)
+            if nw in (2, 4):
+                data.append((r["M"], r["N"], r["K"], mt, nw, s_, ns, t))
+    refit2 = "--refit2" in sys.argv
 
-    def loss(p):
-        return sum(math.log(model(p, *d[:6]) / d[6]) ** 2 for d in data) / len(data)
+    def fit(p, idx, pts):
+        def loss(q):
+            return sum(math.log(model(q, *d[:7]) / d[7]) ** 2 for d in pts) / max(1, len(pts))
+        best = loss(p)
+        for _ in range(30000):
+            q = list(p)
+            i = random.choice(idx)
+            q[i] *= math.exp(random.gauss(0, 0.07))
+            l = loss(q)
+            if l < best:
+                best, p = l, q
+        return p, best
 
     random.seed(0)
-    p, best = list(INIT), loss(INIT)
-    for _ in range(40000):
-        q = list(p)
-        i = random.randrange(len(p))
-        q[i] *= math.exp(random.gauss(0, 0.08))
-        l = loss(q)
-        if l < best:
-            best, p = l, q
-    print(f"{len(data)} points, r.m.s. log error {math.sqrt(best):.3f}")
+    p = list(INIT)
+    d2, d3 = [d for d in data if d[6] == 2], [d for d in data if d[6] == 3]
+    if refit2 or not d3:
+        p, b2 = fit(p, list(range(N2)), d2)
+        print(f"two-stage classes: {len(d2)} points, r.m.s. log error {math.sqrt(b2):.3f}")
+    if d3:
+        p, b3 = fit(p, list(range(N2, len(NAMES))), d3)
+        print(f"three-stage classes: {len(d3)} points, r.m.s. log error {math.sqrt(b3):.3f}")
     for n, v in zip(NAMES, p):
         print(f"#define GAM_SPM_{n} {v:.3g}")
     tot = n_ = 0
@@ -78,17 +104,15 @@ def main():
             continue
         pred = {}
         for c in cf:
-            mt, rest = c.split("x")
-            nw, s = rest.split("/S")
-            mt, nw, s = int(mt), int(nw), int(s)
+            mt, nw, s, ns = parse(c)
             if nw not in (2, 4):
                 continue
             tiles = cdiv(r["M"], 64 * mt) * cdiv(r["N"], 256 if nw == 4 else 128)
             if s > 1 and tiles * 2 > 256:
                 continue
-            pred[c] = model(p, r["M"], r["N"], r["K"], mt, nw, s)
+            pred[c] = model(p, r["M"], r["N"], r["K"], mt, nw, s, ns)
         ch, bt = min(pred, key=pred.get), min(cf.values())
-        print(f"M={r['M']:6d} N={r['N']:5d} K={r['K']:6d} plan {ch:8s} {cf[ch]:7.1f} us | best {min(cf, key=cf.get):8s} {bt:7.1f} | regret {cf[ch] / bt:.2f}")
+        print(f"M={r['M']:6d} N={r['N']:5d} K={r['K']:6d} plan {ch:11s} {cf[ch]:7.1f} us | best {min(cf, key=cf.get):11s} {bt:7.1f} | regret {cf[ch] / bt:.2f}")
         tot += cf[ch] / bt
         n_ += 1
     print(f"mean regret {tot / max(1, n_):.3f}")
