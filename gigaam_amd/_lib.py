@@ -20,7 +20,7 @@ ATT_ROTARY, ATT_REL_POS = 0, 1
 NORM_BATCH, NORM_LAYER = 0, 1
 HEAD_NONE, HEAD_CTC, HEAD_RNNT, HEAD_EMO = 0, 1, 2, 3
 DTYPE_F32, DTYPE_F16, DTYPE_BF16, DTYPE_F64, DTYPE_I64 = 0, 1, 2, 3, 4
-GEMM_F32, GEMM_F16X3 = 0, 1
+GEMM_F32, GEMM_F16X3, GEMM_F16 = 0, 1, 2
 PF_CLASSES = ["gemm", "conv2", "attn", "norm", "convmod", "stem", "frontend", "decode", "misc"]
 
 

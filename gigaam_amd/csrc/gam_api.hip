@@ -49,6 +49,7 @@ struct W16 {            // split-fp16 planes of one weight matrix (gam_gemm16.h)
   _Float16* hi = nullptr;
   _Float16* lo = nullptr;
   _Float16* sp = nullptr;   // the same planes in the sp32 layout (gam_gemm_sp.h)
+  _Float16* h16 = nullptr;  // GAM_GEMM_F16: the hi plane as the one-term kernel walks it (= hi; a tap-permuted copy for the stem conv)
   float inv = 1.0f;
 };
 
@@ -247,7 +248,23 @@ int make_split(gam_handle* h, const std::vector<float>& w, W16& out, int K = 0, 
   if (hipMemcpy(dl, lo.data(), w.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return -2;
   out.hi = (_Float16*)dh;
   out.lo = (_Float16*)dl;
+  out.h16 = out.hi;
   out.inv = ldexpf(1.0f, -shift);
+  if (conv_taps > 0 && K > 0 && (K / conv_taps) % 64 == 0 && w.size() % (size_t)K == 0) {
+    // one-term kernel, implicit-GEMM A operand: k-tile = 64 channels of one tap, taps innermost within a 64-channel block
+    const size_t C = (size_t)K / conv_taps, cb64 = C / 64;
+    std::vector<uint16_t> hp(w.size());
+    for (size_t n = 0; n < w.size() / K; ++n)
+      for (size_t cb = 0; cb < cb64; ++cb)
+        for (size_t t = 0; t < (size_t)conv_taps; ++t)
+          for (size_t j = 0; j < 64; ++j)
+            hp[n * K + (cb * conv_taps + t) * 64 + j] = hi[n * K + t * C + cb * 64 + j];
+    void* dp = nullptr;
+    if (hipMalloc(&dp, hp.size() * 2 + 64) != hipSuccess) return -2;
+    h->owned.push_back(dp);
+    if (hipMemcpy(dp, hp.data(), hp.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return -2;
+    out.h16 = (_Float16*)dp;
+  }
   if (K > 0 && K % 32 == 0 && w.size() % (size_t)K == 0) {
     // the same planes in the sp32 layout: row n, k-block kb -> [hi x32 | lo x32] (gam_gemm_sp.h)
     std::vector<uint16_t> sp(w.size() * 2);
@@ -323,13 +340,16 @@ int flush_pending(gam_handle* h, hipStream_t s, PendingReduce* p) {
   return 0;
 }
 
+// the split-fp16 arithmetic family: GAM_GEMM_F16X3 (three terms, fp32-equivalent, the default) and GAM_GEMM_F16 (one term, opt-in)
+static inline bool split_mode(const gam_handle* h) { return h->gemm_mode != GAM_GEMM_F32; }
+
 int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls = GAM_PF_GEMM, const W16* w16 = nullptr,
          PendingReduce* defer = nullptr) {
   GamGemmArgs a = a_in;
   if (int r = flush_pending(h, s, defer)) return r;   // (an unconsumed deferral must not be overwritten: its C would stay unreduced)
   a.range_flag = h->use_range ? h->range_flag : nullptr;
-  if (h->gemm_mode != GAM_GEMM_F16X3) a.c_guard = 0;   // fp32 consumers have no range limit
-  if (h->gemm_mode != GAM_GEMM_F16X3 || w16 == nullptr || w16->hi == nullptr) a.a_rs = nullptr;   // exact-fp32 path: A is never scaled
+  if (!split_mode(h)) a.c_guard = 0;   // fp32 consumers have no range limit
+  if (!split_mode(h) || w16 == nullptr || w16->hi == nullptr) a.a_rs = nullptr;   // exact-fp32 path: A is never scaled
   ProfScope ps(h, s, cls, 2.0 * (double)a.M * (double)a.N * (double)a.K);
   if (ps.ev) {   // unique bytes: A (overlapping rows counted once), W, C (+ residual)
     const double abytes = a.a_mode == 0 ? ((double)(a.M - 1) * (double)std::min<long>(a.lda, a.K) + a.K) * 4.0
@@ -337,11 +357,20 @@ int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls
     h->prof_bytes[cls] += abytes * (a.n_switch > 0 ? 2.0 : 1.0) + 4.0 * a.N * a.K + 4.0 * a.M * a.N * (a.R ? 2.0 : 1.0);   // (n_switch: two A operands)
   }
   hipError_t e;
-  const bool f16 = h->gemm_mode == 1 && w16 != nullptr && w16->hi != nullptr;
+  const bool f16 = split_mode(h) && w16 != nullptr && w16->hi != nullptr;
   if (f16 && a.Asp != nullptr) {
     if (w16->sp == nullptr) return fail(h, -2, "sp32 A without sp32 W planes");
     a.Whi = w16->hi; a.Wlo = w16->lo; a.wscale_inv = w16->inv;
     a.Wsp = w16->sp;
+    a.h16 = 0;
+    if (a.a_fmt == 2) {
+      // one fp16 MFMA per product: plain-fp16 operands (the producers wrote format 2), and the kernel is told HALF the
+      // reduction length -- 64 fp16 values fill the 128-byte line that holds 32 (hi, lo) pairs in the three-term layout
+      if (a.K % 64 != 0 || (a.a_mode == 0 ? a.lda % 64 != 0 : a.conv_c % 64 != 0) || w16->h16 == nullptr)
+        return fail(h, -2, "GAM_GEMM_F16: K / row pitch of a GEMM operand is not a multiple of 64 (M=%d N=%d K=%d)", a.M, a.N, a.K);
+      a.h16 = 1; a.K /= 2; a.lda /= 2; a.conv_c /= 2;
+      a.Wsp = w16->h16;
+    }
     GamSpPlan plan = gam_gemm_sp_plan(a.M, a.N, a.K, a.a_mode, h->ncu);
     if (!h->use_splitk) plan.s = 1;   // GAM_SPLITK=0: the A/B switch covers this path too (tile shape as planned)
     a.sp_mt = plan.mt; a.sp_nw = plan.nw; a.sp_ns = plan.ns;
@@ -457,7 +486,8 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   }
   if (const char* e = getenv("GAM_ROWSCALE")) h->use_rowscale = atoi(e);
   if (const char* e = getenv("GAM_RANGE")) h->use_range = atoi(e);
-  if (const char* e = getenv("GAM_GEMM_MODE")) h->gemm_mode = (strcmp(e, "f32") == 0) ? GAM_GEMM_F32 : GAM_GEMM_F16X3;
+  if (const char* e = getenv("GAM_GEMM_MODE"))
+    h->gemm_mode = strcmp(e, "f32") == 0 ? GAM_GEMM_F32 : (strcmp(e, "f16") == 0 ? GAM_GEMM_F16 : GAM_GEMM_F16X3);
   const gam_config& c = h->cfg;
   if (c.d_model <= 0 || c.n_heads <= 0 || c.d_model % c.n_heads != 0)
     return fail(h, -1, "bad d_model/n_heads %d/%d", c.d_model, c.n_heads);
@@ -964,8 +994,9 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
   // Large batches: every big GEMM runs on the LDS-DMA kernel of gam_gemm_sp.h, and the kernels that
   // produce its A operands (LayerNorm, SiLU epilogue, attention, conv module, stem) write them in the
   // sp32 split layout instead of fp32 -- same bytes, no conversion pass.
-  const bool sp = h->gemm_mode == GAM_GEMM_F16X3 && h->use_sp && N >= h->sp_min_m && D % 32 == 0 && DFF % 32 == 0;
-  auto sp_a = [&](GamGemmArgs& g) { if (sp) g.Asp = reinterpret_cast<const _Float16*>(g.A); };
+  const bool sp = split_mode(h) && h->use_sp && N >= h->sp_min_m && D % 32 == 0 && DFF % 32 == 0;
+  const int spf = sp ? (h->gemm_mode == GAM_GEMM_F16 ? 2 : 1) : 0;   // operand format the producers write (gam_common.h gam_store4)
+  auto sp_a = [&](GamGemmArgs& g) { if (sp) { g.Asp = reinterpret_cast<const _Float16*>(g.A); g.a_fmt = spf; } };
 
   // ------------------------------ stem ------------------------------
   if (conv2d) {
@@ -976,18 +1007,21 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       GamConv1Args a;
       a.feat = feat; a.img = h->img.p; a.w = h->c1_w; a.bias = h->c1_b; a.len0 = len0; a.len1 = len1;
       a.B = B; a.T = (int)T; a.F = F; a.Ta = Ta; a.FP = FP; a.C = C; a.T1 = T1;
-      a.img_split = sp && C % 32 == 0;
+      a.img_split = (sp && C % 32 == 0) ? spf : 0;
       a.range_flag = h->use_range ? h->range_flag : nullptr;
       ProfScope ps(h, s, GAM_PF_STEM, (double)B * 2 * Ta * FP * C * 4.0);
       hipLaunchKernelGGL(gam_conv2d1_kernel, dim3(2 * Ta, B), dim3(256), 0, s, a);
       HIPCHK(h, hipGetLastError());
       // two slack rows past the last utterance (read by its padding frame only)
-      HIPCHK(h, hipMemsetAsync(h->img.p + (size_t)B * 2 * Ta * FP * C, 0, (size_t)2 * FP * C * sizeof(float), s));
+      // two slack rows past the last utterance (read by its padding frame only); the dense fp16 image ends at half the offset
+      const size_t img_end = (size_t)B * 2 * Ta * FP * C;
+      HIPCHK(h, hipMemsetAsync(a.img_split == 2 ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(h->img.p) + img_end) : h->img.p + img_end, 0,
+                               (size_t)2 * FP * C * sizeof(float), s));
     }
     GamGemmArgs g = gemm_args(h->img.p, 0, h->c2_w, h->c2_b, h->c2.p, C, N * F2, C, 9 * C);
     g.a_mode = 1; g.conv_fp = FP; g.conv_c = C; g.conv_f2 = F2;
     g.lens = len2; g.rpb = Ta * F2; g.fdiv = F2;
-    if (sp && C % 32 == 0) { sp_a(g); g.c_split = 1; }
+    if (sp && C % 32 == 0) { sp_a(g); g.c_split = spf; }
     g.c_guard = 1;
     if (int r = gemm(h, s, g, GAM_ACT_RELU, GAM_PF_CONV2, &h->s_c2)) return r;
     GamGemmArgs l = gemm_args(h->c2.p, (long)F2 * C, h->lin_w, h->lin_b, h->x.p, D, N, D, F2 * C);
@@ -1029,12 +1063,12 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
   ln.rows = N; ln.d = D; ln.ta = Ta; ln.dk = dk; ln.eps = 1e-5f; ln.rcos = h->rot_cos; ln.rsin = h->rot_sin;
   ln.rope_rows = c.pos_emb_max_len;
   // split-fp16 modes: every LayerNorm hands its GEMMs a per-row power-of-two scale (gam_row_scale)
-  float* const rs = h->gemm_mode == GAM_GEMM_F16X3 && h->use_rowscale ? h->rsbuf.p : nullptr;
+  float* const rs = split_mode(h) && h->use_rowscale ? h->rsbuf.p : nullptr;
   ln.rs = rs;
   if (nl > 0) {
     GamLnArgs a = ln;
     a.x = h->x.p; a.out1 = h->y.p; a.w1 = h->layers[0].ln_ff1_w; a.b1 = h->layers[0].ln_ff1_b;
-    a.split1 = sp;
+    a.split1 = spf;
     if (int r = layernorm(h, s, a, 0)) return r;
   }
   PendingReduce pend;    // the split-K slices of the residual GEMM just launched, summed by the LayerNorm that follows it
@@ -1043,7 +1077,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     // --- FFN 1 (macaron half step) ---
     {
       GamGemmArgs g = gemm_args(h->y.p, D, L.ff1_w1, L.ff1_b1, h->hbuf.p, DFF, N, DFF, D);
-      sp_a(g); g.c_split = sp; g.a_rs = rs; g.c_guard = 1;
+      sp_a(g); g.c_split = spf; g.a_rs = rs; g.c_guard = 1;
       if (int r = gemm(h, s, g, GAM_ACT_SILU, GAM_PF_GEMM, &L.s_ff1_w1)) return r;
       GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff1_w2, L.ff1_b2, h->x.p, D, N, D, DFF);
       g2.R = h->x.p; g2.ldr = D; g2.alpha = 0.5f;
@@ -1054,7 +1088,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     {
       GamLnArgs a = ln;
       a.x = h->x.p; a.out1 = h->y.p; a.out2 = h->yr.p; a.w1 = L.ln_att_w; a.b1 = L.ln_att_b;
-      a.split1 = sp; a.split2 = sp;
+      a.split1 = spf; a.split2 = spf;
       if (int r = layernorm(h, s, a, rel ? 0 : 1, &pend)) return r;
       // rotary: q,k project the rotated copy, v the plain one; rel_pos: all three project y.  One [N, 3D] result q | k | v.
       // q, k and v are split to fp16 unscaled by the attention kernel: range guard on all of them.
@@ -1083,14 +1117,14 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       }
       GamAttnArgs at;
       memset(&at, 0, sizeof at);
-      at.q = h->qkv.p; at.k = h->qkv.p + D; at.v = h->qkv.p + 2 * D; at.ctx = h->ctx.p; at.ctx_split = sp;
+      at.q = h->qkv.p; at.k = h->qkv.p + D; at.v = h->qkv.p + 2 * D; at.ctx = h->ctx.p; at.ctx_split = spf;
       at.lens = B > 1 ? len2 : nullptr;  // encoder.py:620-624: no mask at batch 1
       at.B = B; at.Ta = Ta; at.Tv = Tv; at.H = H; at.ldq = 3 * D; at.ldv = 3 * D; at.ldo = D;
       at.scale = 1.0f / sqrtf((float)dk);
       at.pbuf = rel ? h->pbuf.p : nullptr; at.pos_u = L.pos_u; at.pos_v = L.pos_v; at.ldp = D;
       {
         ProfScope ps(h, s, GAM_PF_ATTN, 4.0 * (double)B * H * (double)Tv * Tv * dk);
-        hipError_t e = gam_launch_attn_mode(at, dk, h->gemm_mode == GAM_GEMM_F16X3, s);
+        hipError_t e = gam_launch_attn_mode(at, dk, split_mode(h), s, h->gemm_mode == GAM_GEMM_F16 ? 1 : 3);
         if (e != hipSuccess) return fail(h, -2, "attention launch: %s", hipGetErrorString(e));
       }
       GamGemmArgs go = gemm_args(h->ctx.p, D, L.wo, L.bo, h->x.p, D, N, D, D);
@@ -1102,7 +1136,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     {
       GamLnArgs a = ln;
       a.x = h->x.p; a.out1 = h->y.p; a.w1 = L.ln_conv_w; a.b1 = L.ln_conv_b;
-      a.split1 = sp;
+      a.split1 = spf;
       if (int r = layernorm(h, s, a, 0, &pend)) return r;
       GamGemmArgs g1 = gemm_args(h->y.p, D, L.pw1_w, L.pw1_b, h->ubuf.p, 2 * D, N, 2 * D, D);
       sp_a(g1); g1.a_rs = rs;
@@ -1110,7 +1144,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       GamConvModArgs cm;
       cm.u = h->ubuf.p; cm.z = h->zbuf.p; cm.dw_w = L.dw_w; cm.dw_b = L.dw_b; cm.n_scale = L.cn_scale; cm.n_shift = L.cn_shift;
       cm.lens = len2; cm.B = B; cm.Ta = Ta; cm.Tv = Tv; cm.d = D; cm.ks = c.conv_kernel_size; cm.eps = 1e-5f;
-      cm.z_split = sp; cm.range_flag = h->use_range ? h->range_flag : nullptr;
+      cm.z_split = spf; cm.range_flag = h->use_range ? h->range_flag : nullptr;
       {
         ProfScope ps(h, s, GAM_PF_CONVMOD, (double)N * D * 3 * 4.0);
         hipError_t e = gam_launch_convmod(cm, c.conv_norm_type == GAM_NORM_LAYER, s);
@@ -1125,10 +1159,10 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     {
       GamLnArgs a = ln;
       a.x = h->x.p; a.out1 = h->y.p; a.w1 = L.ln_ff2_w; a.b1 = L.ln_ff2_b;
-      a.split1 = sp;
+      a.split1 = spf;
       if (int r = layernorm(h, s, a, 0, &pend)) return r;
       GamGemmArgs g = gemm_args(h->y.p, D, L.ff2_w1, L.ff2_b1, h->hbuf.p, DFF, N, DFF, D);
-      sp_a(g); g.c_split = sp; g.a_rs = rs; g.c_guard = 1;
+      sp_a(g); g.c_split = spf; g.a_rs = rs; g.c_guard = 1;
       if (int r = gemm(h, s, g, GAM_ACT_SILU, GAM_PF_GEMM, &L.s_ff2_w1)) return r;
       GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff2_w2, L.ff2_b2, h->x.p, D, N, D, DFF);
       g2.R = h->x.p; g2.ldr = D; g2.alpha = 0.5f;
@@ -1141,7 +1175,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       a.x = h->x.p; a.out1 = h->x.p; a.w1 = L.ln_out_w; a.b1 = L.ln_out_b;
       if (li + 1 < nl) {
         a.out2 = h->y.p; a.w2 = h->layers[li + 1].ln_ff1_w; a.b2 = h->layers[li + 1].ln_ff1_b;
-        a.split2 = sp;
+        a.split2 = spf;
         if (int r = layernorm(h, s, a, 2, &pend)) return r;
       } else {
         a.rs = nullptr;   // the last norm_out feeds no GEMM
@@ -1394,7 +1428,7 @@ int gam_op_gemm(gam_handle* h, const float* A, const float* W, const float* bias
   if (!h) return -1;
   HIPCHK(h, hipSetDevice(h->device));
   GamGemmArgs g = gemm_args(A, K, W, bias, C, N, M, N, K);
-  if (h->gemm_mode != GAM_GEMM_F16X3) return gemm(h, (hipStream_t)stream, g, act);
+  if (!split_mode(h)) return gemm(h, (hipStream_t)stream, g, act);
   // split-fp16 mode: the W planes are rebuilt on the device (unit scale) on every call -- a cache keyed
   // on the W pointer returned stale planes when an allocator handed the same address to a new matrix
   // of the same size.  This is a test / microbenchmark entry; the HIP-event profile class times only
@@ -1409,6 +1443,7 @@ int gam_op_gemm(gam_handle* h, const float* A, const float* W, const float* bias
   }
   W16 w16;
   w16.hi = (_Float16*)h->op_planes.p; w16.lo = w16.hi + count + 8; w16.inv = 1.0f;
+  w16.h16 = w16.hi;
   // per-row power-of-two scale of A, as the LayerNorm kernels provide it inside the encoder
   if (int r = ensure(h, h->op_rs, (size_t)M + 64)) return r;
   hipLaunchKernelGGL(gam_rowscale_kernel, dim3(gam_cdiv(M, 4)), dim3(256), 0, s, A, h->op_rs.p, M, K, (long)K);
@@ -1421,8 +1456,13 @@ int gam_op_gemm(gam_handle* h, const float* A, const float* W, const float* bias
     hipLaunchKernelGGL(gam_to_sp32_kernel, dim3((int)std::min<size_t>((wn / 4 + 255) / 256, 4096)), dim3(256), 0, s, W,
                        (_Float16*)h->op_sp.p, wn / 4, (const float*)nullptr, K);
     if (int r = ensure(h, h->aplanes, an + 64)) return r;
-    hipLaunchKernelGGL(gam_to_sp32_kernel, dim3((int)std::min<size_t>((an / 4 + 255) / 256, 8192)), dim3(256), 0, s, A,
-                       (_Float16*)h->aplanes.p, an / 4, (const float*)h->op_rs.p, K);
+    g.a_fmt = (h->gemm_mode == GAM_GEMM_F16 && K % 64 == 0) ? 2 : 1;   // (other K: the three-term kernels, whatever the mode)
+    if (g.a_fmt == 2)
+      hipLaunchKernelGGL(gam_to_h16_kernel, dim3((int)std::min<size_t>((an / 4 + 255) / 256, 8192)), dim3(256), 0, s, A,
+                         (_Float16*)h->aplanes.p, an / 4, (const float*)h->op_rs.p, K);
+    else
+      hipLaunchKernelGGL(gam_to_sp32_kernel, dim3((int)std::min<size_t>((an / 4 + 255) / 256, 8192)), dim3(256), 0, s, A,
+                         (_Float16*)h->aplanes.p, an / 4, (const float*)h->op_rs.p, K);
     w16.sp = (_Float16*)h->op_sp.p;
     g.Asp = (const _Float16*)h->aplanes.p;
   } else if (K % 4 == 0) {   // 128x128 kernel: a row-scaled fp32 copy of A (what the LayerNorm kernels write inside the encoder)
@@ -1448,13 +1488,13 @@ int gam_op_attention(gam_handle* h, const float* q, const float* k, const float*
   at.q = q; at.k = k; at.v = v; at.ctx = ctx; at.lens = lens;
   at.B = B; at.Ta = T; at.Tv = T; at.H = H; at.ldq = D; at.ldv = D; at.ldo = D;
   at.scale = 1.0f / sqrtf((float)GAM_ATT_DK);
-  hipError_t e = gam_launch_attn_mode(at, GAM_ATT_DK, h->gemm_mode == GAM_GEMM_F16X3, (hipStream_t)stream);
+  hipError_t e = gam_launch_attn_mode(at, GAM_ATT_DK, split_mode(h), (hipStream_t)stream, h->gemm_mode == GAM_GEMM_F16 ? 1 : 3);
   if (e != hipSuccess) return fail(h, -2, "attention launch: %s", hipGetErrorString(e));
   return 0;
 }
 
 int gam_set_gemm_mode(gam_handle* h, int mode) {
-  if (!h || (mode != GAM_GEMM_F32 && mode != GAM_GEMM_F16X3)) return fail(h, -1, "unknown GEMM mode %d", mode);
+  if (!h || (mode != GAM_GEMM_F32 && mode != GAM_GEMM_F16X3 && mode != GAM_GEMM_F16)) return fail(h, -1, "unknown GEMM mode %d", mode);
   h->gemm_mode = mode;
   return 0;
 }

@@ -36,9 +36,14 @@ __device__ __forceinline__ void gam_split8(const float (&v)[8], gam_half8& hi, g
 #ifndef GAM_ATT_NJ
 #define GAM_ATT_NJ 2   // 16-query sub-blocks per wave (A/B switch: 1 = 64 queries per workgroup, twice the waves per SIMD)
 #endif
-template <bool REL>
+// TERMS = 3: the three-term split above (fp32-equivalent).  TERMS = 1 (GAM_GEMM_F16, the opt-in speed mode): hi planes only --
+// K, V, Q and P are rounded to fp16 once, one MFMA per product, fp32 accumulation and fp32 softmax statistics: the arithmetic of
+// an fp16 flash attention (the reference's GPU default runs SDPA under fp16 autocast, /root/reference/gigaam/model.py:34-37).
+// The lo planes are neither computed nor stored (the compiler drops the dead halves of the splits).
+template <bool REL, int TERMS = 3>
 __global__ __launch_bounds__(256, GAM_ATT_NJ == 1 ? 4 : 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
   constexpr int NJ = GAM_ATT_NJ;
+  constexpr bool LO = TERMS == 3;
   a.scale *= 1.44269504088896341f;   // softmax via 2^x: p = 2^(s*log2e - m)
   __shared__ float Gs[REL ? 4 * 80 * 17 : 1];   // per wave: (q+v).P for 80 relative positions x 16 queries
   __shared__ __attribute__((aligned(16))) _Float16 Kh[GAM_ATT_KT * GAM_A16_KLD];
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256, GAM_ATT_NJ == 1 ? 4 : 2) void gam_attn_f16x3_k
         gam_half4 hi, lo;
         gam_split4((f32x4){kv.x, kv.y, kv.z, kv.w}, hi, lo);
         *reinterpret_cast<gam_half4*>(&Kh[kr * GAM_A16_KLD + c4]) = hi;
-        *reinterpret_cast<gam_half4*>(&Kl[kr * GAM_A16_KLD + c4]) = lo;
+        if (LO) *reinterpret_cast<gam_half4*>(&Kl[kr * GAM_A16_KLD + c4]) = lo;
       }
       // V^T: one item = 2 neighbouring keys x 4 channels -> per channel one 4-byte write per plane
       for (int it = tid; it < 32 * 12; it += 256) {
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256, GAM_ATT_NJ == 1 ? 4 : 2) void gam_attn_f16x3_k
   #pragma unroll
         for (int e = 0; e < 4; ++e) {
           *reinterpret_cast<half2_t*>(&Vh[(c4 + e) * GAM_A16_VLD + 2 * kp]) = (half2_t){h0[e], h1[e]};
-          *reinterpret_cast<half2_t*>(&Vl[(c4 + e) * GAM_A16_VLD + 2 * kp]) = (half2_t){l0[e], l1[e]};
+          if (LO) *reinterpret_cast<half2_t*>(&Vl[(c4 + e) * GAM_A16_VLD + 2 * kp]) = (half2_t){l0[e], l1[e]};
         }
       }
     } else {
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(256, GAM_ATT_NJ == 1 ? 4 : 2) void gam_attn_f16x3_k
         gam_half4 hi, lo;
         gam_split4((f32x4){kreg[i].x, kreg[i].y, kreg[i].z, kreg[i].w}, hi, lo);
         *reinterpret_cast<gam_half4*>(&Kh[kr * GAM_A16_KLD + c4]) = hi;
-        *reinterpret_cast<gam_half4*>(&Kl[kr * GAM_A16_KLD + c4]) = lo;
+        if (LO) *reinterpret_cast<gam_half4*>(&Kl[kr * GAM_A16_KLD + c4]) = lo;
       }
       // V^T: one item = 2 neighbouring keys x 4 channels -> per channel one 4-byte write per plane
   #pragma unroll
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256, GAM_ATT_NJ == 1 ? 4 : 2) void gam_attn_f16x3_k
   #pragma unroll
           for (int e = 0; e < 4; ++e) {
             *reinterpret_cast<half2_t*>(&Vh[(c4 + e) * GAM_A16_VLD + 2 * kp]) = (half2_t){h0[e], h1[e]};
-            *reinterpret_cast<half2_t*>(&Vl[(c4 + e) * GAM_A16_VLD + 2 * kp]) = (half2_t){l0[e], l1[e]};
+            if (LO) *reinterpret_cast<half2_t*>(&Vl[(c4 + e) * GAM_A16_VLD + 2 * kp]) = (half2_t){l0[e], l1[e]};
           }
         }
       }
@@ -194,9 +199,13 @@ __global__ __launch_bounds__(256, GAM_ATT_NJ == 1 ? 4 : 2) void gam_attn_f16x3_k
     for (int kb = 0; kb < 4; ++kb) {
       const int ko = (kb * 16 + li) * GAM_A16_KLD;
       const gam_half8 kh32 = *reinterpret_cast<const gam_half8*>(&Kh[ko + 8 * lg]);
-      const gam_half8 kl32 = *reinterpret_cast<const gam_half8*>(&Kl[ko + 8 * lg]);
       const gam_half4 kh16 = *reinterpret_cast<const gam_half4*>(&Kh[ko + 32 + 4 * lg]);
-      const gam_half4 kl16 = *reinterpret_cast<const gam_half4*>(&Kl[ko + 32 + 4 * lg]);
+      gam_half8 kl32 = kh32;
+      gam_half4 kl16 = kh16;
+      if (LO) {
+        kl32 = *reinterpret_cast<const gam_half8*>(&Kl[ko + 8 * lg]);
+        kl16 = *reinterpret_cast<const gam_half4*>(&Kl[ko + 32 + 4 * lg]);
+      }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         // Two accumulator chains, one per instruction shape: a 4-pass 16x16x16 MFMA issued
@@ -205,10 +214,12 @@ __global__ __launch_bounds__(256, GAM_ATT_NJ == 1 ? 4 : 2) void gam_attn_f16x3_k
         // dependent chains are safe (the GEMMs rely on them); the two sums are added on the VALU.
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 s16 = (f32x4){0.f, 0.f, 0.f, 0.f};
-        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl32, qh32[j], s, 0, 0, 0);
-        s16 = __builtin_amdgcn_mfma_f32_16x16x16f16(kl16, qh16[j], s16, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh32, ql32[j], s, 0, 0, 0);
-        s16 = __builtin_amdgcn_mfma_f32_16x16x16f16(kh16, ql16[j], s16, 0, 0, 0);
+        if (LO) {
+          s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl32, qh32[j], s, 0, 0, 0);
+          s16 = __builtin_amdgcn_mfma_f32_16x16x16f16(kl16, qh16[j], s16, 0, 0, 0);
+          s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh32, ql32[j], s, 0, 0, 0);
+          s16 = __builtin_amdgcn_mfma_f32_16x16x16f16(kh16, ql16[j], s16, 0, 0, 0);
+        }
         s = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh32, qh32[j], s, 0, 0, 0);
         s16 = __builtin_amdgcn_mfma_f32_16x16x16f16(kh16, qh16[j], s16, 0, 0, 0);
         s += s16;
@@ -237,10 +248,12 @@ __global__ __launch_bounds__(256, GAM_ATT_NJ == 1 ? 4 : 2) void gam_attn_f16x3_k
           gam_split4((f32x4){p2.x, p2.y, p2.z, p2.w}, ph16, pl16);
           f32x4 g = (f32x4){0.f, 0.f, 0.f, 0.f};
           f32x4 g16 = (f32x4){0.f, 0.f, 0.f, 0.f};   // one chain per MFMA shape (see below)
-          g = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl32, gh32[j], g, 0, 0, 0);
-          g16 = __builtin_amdgcn_mfma_f32_16x16x16f16(pl16, gh16[j], g16, 0, 0, 0);
-          g = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph32, gl32[j], g, 0, 0, 0);
-          g16 = __builtin_amdgcn_mfma_f32_16x16x16f16(ph16, gl16[j], g16, 0, 0, 0);
+          if (LO) {
+            g = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl32, gh32[j], g, 0, 0, 0);
+            g16 = __builtin_amdgcn_mfma_f32_16x16x16f16(pl16, gh16[j], g16, 0, 0, 0);
+            g = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph32, gl32[j], g, 0, 0, 0);
+            g16 = __builtin_amdgcn_mfma_f32_16x16x16f16(ph16, gl16[j], g16, 0, 0, 0);
+          }
           g = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph32, gh32[j], g, 0, 0, 0);
           g16 = __builtin_amdgcn_mfma_f32_16x16x16f16(ph16, gh16[j], g16, 0, 0, 0);
           g += g16;
@@ -317,14 +330,19 @@ __global__ __launch_bounds__(256, GAM_ATT_NJ == 1 ? 4 : 2) void gam_attn_f16x3_k
         const int vo = (d * 16 + li) * GAM_A16_VLD + 4 * lg;
         const gam_half4 vh0 = *reinterpret_cast<const gam_half4*>(&Vh[vo + (2 * c) * 16]);
         const gam_half4 vh1 = *reinterpret_cast<const gam_half4*>(&Vh[vo + (2 * c + 1) * 16]);
-        const gam_half4 vl0 = *reinterpret_cast<const gam_half4*>(&Vl[vo + (2 * c) * 16]);
-        const gam_half4 vl1 = *reinterpret_cast<const gam_half4*>(&Vl[vo + (2 * c + 1) * 16]);
         const gam_half8 vh = {vh0[0], vh0[1], vh0[2], vh0[3], vh1[0], vh1[1], vh1[2], vh1[3]};
-        const gam_half8 vl = {vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
+        gam_half8 vl = vh;
+        if (LO) {
+          const gam_half4 vl0 = *reinterpret_cast<const gam_half4*>(&Vl[vo + (2 * c) * 16]);
+          const gam_half4 vl1 = *reinterpret_cast<const gam_half4*>(&Vl[vo + (2 * c + 1) * 16]);
+          vl = (gam_half8){vl0[0], vl0[1], vl0[2], vl0[3], vl1[0], vl1[1], vl1[2], vl1[3]};
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          o[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[j], o[d][j], 0, 0, 0);
-          o[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[j], o[d][j], 0, 0, 0);
+          if (LO) {
+            o[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[j], o[d][j], 0, 0, 0);
+            o[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[j], o[d][j], 0, 0, 0);
+          }
           o[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[j], o[d][j], 0, 0, 0);
         }
       }
@@ -349,11 +367,17 @@ __global__ __launch_bounds__(256, GAM_ATT_NJ == 1 ? 4 : 2) void gam_attn_f16x3_k
 }
 
 // split = true: fp16-split MFMA path; false: exact-fp32 MFMA path (gam_attn.h)
-static inline hipError_t gam_launch_attn_mode(const GamAttnArgs& a, int dk, bool split, hipStream_t s) {
+// terms = 3: the three-term split (GAM_GEMM_F16X3); terms = 1: hi planes only (GAM_GEMM_F16, opt-in)
+static inline hipError_t gam_launch_attn_mode(const GamAttnArgs& a, int dk, bool split, hipStream_t s, int terms = 3) {
   if (!split) return gam_launch_attn(a, dk, s);
   if (dk != GAM_ATT_DK) return hipErrorInvalidValue;
   dim3 grid(gam_cdiv(a.Ta, 64 * GAM_ATT_NJ), a.H, a.B);
-  if (a.pbuf != nullptr) hipLaunchKernelGGL(gam_attn_f16x3_kernel<true>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(gam_attn_f16x3_kernel<false>, grid, dim3(256), 0, s, a);
+  if (terms == 1) {
+    if (a.pbuf != nullptr) hipLaunchKernelGGL((gam_attn_f16x3_kernel<true, 1>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gam_attn_f16x3_kernel<false, 1>), grid, dim3(256), 0, s, a);
+  } else {
+    if (a.pbuf != nullptr) hipLaunchKernelGGL((gam_attn_f16x3_kernel<true, 3>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gam_attn_f16x3_kernel<false, 3>), grid, dim3(256), 0, s, a);
+  }
   return hipGetLastError();
 }

@@ -101,10 +101,14 @@ __device__ __forceinline__ void gam_range_note(int* flag, float a, float b, floa
 // Activation stores.  `base` + `row_off` (elements, a multiple of 32) is the start of a row; c is
 // the column.  split = 0: plain fp32.  split = 1: the sp32 layout of gam_gemm_sp.h -- the row's
 // 32-element block c/32 holds [hi x32 | lo x32] fp16 in the 128 bytes the fp32 values would take.
+// split = 2 (GAM_GEMM_F16, the opt-in one-term mode): plain fp16 rows -- element (row, c) is the half at row_off + c of the
+// same buffer viewed as halfs (the first half of the bytes the fp32 tensor would take; row pitch = the row length).
 __device__ __forceinline__ void gam_store4(float* base, size_t row_off, int c, float x0, float x1, float x2, float x3,
                                            int split) {   // c % 4 == 0
   if (!split) {
     *reinterpret_cast<f32x4*>(base + row_off + c) = (f32x4){x0, x1, x2, x3};
+  } else if (split == 2) {
+    *reinterpret_cast<gam_half4*>(reinterpret_cast<_Float16*>(base) + row_off + c) = __builtin_convertvector((f32x4){x0, x1, x2, x3}, gam_half4);
   } else {
     _Float16* p = reinterpret_cast<_Float16*>(base) + row_off * 2 + (c >> 5) * 64 + (c & 31);
     gam_half4 hi, lo;
@@ -116,6 +120,8 @@ __device__ __forceinline__ void gam_store4(float* base, size_t row_off, int c, f
 __device__ __forceinline__ void gam_store2(float* base, size_t row_off, int c, float x0, float x1, int split) {   // c % 2 == 0
   if (!split) {
     *reinterpret_cast<float2*>(base + row_off + c) = make_float2(x0, x1);
+  } else if (split == 2) {
+    *reinterpret_cast<gam_half2*>(reinterpret_cast<_Float16*>(base) + row_off + c) = __builtin_convertvector((f32x2){x0, x1}, gam_half2);
   } else {
     _Float16* p = reinterpret_cast<_Float16*>(base) + row_off * 2 + (c >> 5) * 64 + (c & 31);
     unsigned h, l;
@@ -127,6 +133,8 @@ __device__ __forceinline__ void gam_store2(float* base, size_t row_off, int c, f
 __device__ __forceinline__ void gam_store1(float* base, size_t row_off, int c, float x, int split) {
   if (!split) {
     base[row_off + c] = x;
+  } else if (split == 2) {
+    reinterpret_cast<_Float16*>(base)[row_off + c] = (_Float16)x;
   } else {
     _Float16* p = reinterpret_cast<_Float16*>(base) + row_off * 2 + (c >> 5) * 64 + (c & 31);
     const _Float16 h = (_Float16)x;

@@ -60,7 +60,7 @@ struct GamGemmArgs {
   // launch for two projections of two operands that share rows, pitch and row scale (q|k of the rotated copy, v of the plain one)
   const _Float16* Asp2;
   int n_switch;
-  int c_split;          // write C in the sp32 layout (row pitch ldc elements) instead of fp32
+  int c_split;          // 1: write C in the sp32 layout (row pitch ldc elements) instead of fp32; 2: as plain fp16 rows (gam_common.h gam_store4)
   // split-K (small grids): grid.y = splitk slices of K; this struct's K is the slice length, ldw the
   // full row pitch of W; slice s reads columns [s*K, (s+1)*K) and writes its raw partial sums to
   // partial[s][M][N]; gam_splitk_reduce_kernel applies the epilogue.  0 / 1 = off.
@@ -69,6 +69,8 @@ struct GamGemmArgs {
   float* partial;
   int sp_mt, sp_nw;     // LDS-DMA GEMM: the plan's tile shape (gam_gemm_sp_plan); 0 = let the launcher plan (no split-K)
   int sp_ns;            // LDS stages of the plan (2 or 3)
+  int a_fmt;            // format of the Asp operand as its producer wrote it: 1 = sp32 (hi, lo) lines, 2 = plain fp16 rows
+  int h16;              // GAM_GEMM_F16 (opt-in speed mode): plain-fp16 operands, one MFMA per product; K / lda / conv_c are HALVED by the caller
   int ntiles;           // set by the launcher
   int dbg;              // experiment switches (GAM_SP_DBG), 0 in production
   float wscale_inv;     // 2^-wshift, applied to the accumulator in the epilogue
@@ -379,7 +381,7 @@ __global__ __launch_bounds__(256) void gam_splitk_reduce_kernel(GamGemmArgs g, i
     }
     if (VEC == 4) {
       if (g.c_guard) gam_range_note(g.range_flag, v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]);
-      if (g.c_split) gam_store4(g.C, (size_t)orow * g.ldc, col, v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC], 1);
+      if (g.c_split) gam_store4(g.C, (size_t)orow * g.ldc, col, v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC], g.c_split);
       else *reinterpret_cast<f32x4*>(g.C + orow * g.ldc + col) = (f32x4){v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]};
     } else {
       if (g.c_guard) gam_range_note(g.range_flag, v[0], 0.f, 0.f, 0.f);

@@ -75,7 +75,17 @@ struct GamGemmSpCfg {
 // the fetch latency (per-workgroup timeline, profiles/r04_gemm_timeline_m2008.txt: 0.78 us per k-tile at M = 2008 whatever the
 // shape).  With three stages TWO k-tiles are in flight: the in-loop wait is a counted vmcnt (the newest tile's pieces may still
 // be outstanding) in front of a bare s_barrier -- __syncthreads() would drain the queue (cdna_hip_programming.md, glds rule).
-template <int ACT, int MT, int NW, int NS = 2>
+// H16 (r04, the opt-in GAM_GEMM_F16 speed mode): ONE fp16 MFMA per product -- the arithmetic contract of the reference's own GPU
+// default (fp16 autocast, /root/reference/gigaam/model.py:34-37), fp32 accumulation.  Both operands are then PLAIN fp16 rows
+// (the producing kernels store format 2 of gam_store4: the fp16 of each value, row-major), and the kernel is told HALF the
+// reduction length: a row's 128-byte share of a "k-tile" holds 64 consecutive fp16 values instead of 32 (hi, lo) pairs, so the
+// DMA, the LDS image, the swizzle and the fragment reads are exactly those of the three-term kernel -- what used to be the lo
+// half of the line is simply the next 32 k-values -- and the MFMA stream multiplies (first half x first half) + (second half x
+// second half): two MFMAs per 32 x 32 x 32 block instead of three per 32 x 32 x 16.  Per unit of K: a third of the matrix
+// work, half the operand bytes.  (A first version kept the sp32 operands and fetched only the hi half of every line: a 64-byte
+// piece of each 128-byte line costs the memory path the whole line, and the kernel ran at half the delivery rate --
+// profiles/r04_fastmode.txt.)
+template <int ACT, int MT, int NW, int NS = 2, bool H16 = false>
 __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(GamGemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gam_smem_sp[];
   using Cfg = GamGemmSpCfg<MT, NW, NS>;
@@ -193,10 +203,13 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
   // both waves of a SIMD sat in it together and the matrix pipe idled ~600 of every 3500 cycles
   // (clock64 instrumentation, GAM_SP_INSTRUMENT build with GAM_SP_DBG=4).  Fragment reads get >= 2/3 of a phase to land.
   gam_half8 fah[2][MT], fal[2][MT], fbh[2][2], fbl[2][2];
-  constexpr int NM = 6 * MT;        // MFMAs per phase: 3 terms x MT x 2 tiles
+  constexpr int NTERM = H16 ? 2 : 3;
+  constexpr int NM = 2 * NTERM * MT;  // MFMAs per phase: terms x MT x 2 tiles
   constexpr int NR = 2 * MT + 4;    // fragment reads per set
   constexpr int NG = NAI + NWI;     // DMA pieces per wave per k-tile
-  static_assert((NR + 1) / 2 + NG <= NM, "phase too short for its reads + DMA pieces");
+  // first MFMA slot that carries a DMA piece: behind the reads where the phase is long enough (three terms), beside them otherwise
+  constexpr int G0 = ((NR + 1) / 2 + NG <= NM) ? (NR + 1) / 2 : 0;
+  static_assert((NR + 1) / 2 <= NM && G0 + NG <= NM, "phase too short for its reads + DMA pieces");
 #define GAM_SPLD(P) (*reinterpret_cast<const gam_half8*>(P))
   // (plain ifs on unrolled loop counters, not nested generic lambdas: those push the fragment arrays to scratch)
 #define GAM_SP_RDITEM(S, Q, ST, OH, OL)                                                           \
@@ -210,14 +223,14 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
 #define GAM_SP_MFMA(S, T)                                                                         \
   {                                                                                               \
     const int term_ = (T) / (2 * MT), i_ = ((T) % (2 * MT)) / 2, j_ = (T) & 1;                    \
+    /* three terms: hi.hi, lo_w.hi_a, hi_w.lo_a;  H16: first-half x first-half, second-half x second-half */ \
     acc[i_][j_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(term_ == 1 ? fbl[S][j_] : fbh[S][j_],    \
-                                                         term_ == 2 ? fal[S][i_] : fah[S][i_], acc[i_][j_], 0, 0, 0); \
+                                                         (H16 ? term_ == 1 : term_ == 2) ? fal[S][i_] : fah[S][i_], acc[i_][j_], 0, 0, 0); \
   }
   // phase<S, DMA>: MFMAs of set S; reads of set 1-S from (rst, roh, rol); DMA pieces of the next tile -> stage istage
   auto phase = [&](auto setc, auto dmac, const unsigned char* rst, int roh, int rol, int istage) {
     constexpr int S = decltype(setc)::value, R = 1 - S;
     constexpr bool DMA = decltype(dmac)::value;
-    constexpr int G0 = (NR + 1) / 2;   // first MFMA slot that carries a DMA piece
     const unsigned char* ab = Ab;
     const unsigned char* wb = Wb;
     unsigned char* sb = gam_smem_sp;
@@ -387,7 +400,10 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
         if (g.R != nullptr) v += rv[j][q];
         if (g.c_guard) gam_range_note(g.range_flag, v.x, v.y, v.z, v.w);
         if ((GAM_SP_DBG(g) & 32) && v.x != 123.456f) continue;   // (experiment: the whole epilogue except its global stores)
-        if (g.c_split) {
+        if (g.c_split == 2) {   // plain fp16 rows (the one-term mode's operand format)
+          _Float16* cp = reinterpret_cast<_Float16*>(g.C) + orow * g.ldc + ecol;
+          *reinterpret_cast<gam_half4*>(cp) = __builtin_convertvector(v, gam_half4);
+        } else if (g.c_split) {
           _Float16* cp = reinterpret_cast<_Float16*>(g.C) + orow * (2 * g.ldc) + (ecol >> 5) * 64 + (ecol & 31);
           gam_half4 hi, lo;
           gam_split4(v, hi, lo);
@@ -411,12 +427,12 @@ static inline bool gam_gemm_sp_epilogue_ok(const GamGemmArgs& a) {
          (a.R == nullptr || (a.ldr % 4 == 0 && al16(a.R)));
 }
 
-template <int ACT, int MT, int NW, int NS = 2>
+template <int ACT, int MT, int NW, int NS = 2, bool H16 = false>
 static inline void gam_launch_gemm_sp_t(const GamGemmArgs& a, int grid, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_devs{0};
   constexpr int smem = GamGemmSpCfg<MT, NW, NS>::SMEM;
   static_assert(smem <= 160 * 1024, "LDS stages do not fit a CU");
-  auto kern = gam_gemm_sp_kernel<ACT, MT, NW, NS>;
+  auto kern = gam_gemm_sp_kernel<ACT, MT, NW, NS, H16>;
   if (gam_set_max_lds(reinterpret_cast<const void*>(kern), smem, attr_devs) != hipSuccess) return;
   hipLaunchKernelGGL(kern, dim3(grid, a.splitk > 1 ? a.splitk : 1), dim3(128 * NW), smem, stream, a);
 }
@@ -531,7 +547,20 @@ static inline hipError_t gam_launch_gemm_sp(const GamGemmArgs& a_in, int act, hi
   }
 #endif
 #define GAM_LSP(ACTV)                                                            \
-  if (ns == 3) {                                                                 \
+  if (a.h16) {   /* (K, lda, conv_c arrive halved: gam_api.hip gemm()) */        \
+    if (ns == 3) {                                                               \
+      if (nw == 4) gam_launch_gemm_sp_t<ACTV, 2, 4, 3, true>(a, grid, stream);   \
+      else if (mt == 2) gam_launch_gemm_sp_t<ACTV, 2, 2, 3, true>(a, grid, stream); \
+      else gam_launch_gemm_sp_t<ACTV, 3, 2, 3, true>(a, grid, stream);           \
+    } else if (nw == 2) {                                                        \
+      if (mt == 2) gam_launch_gemm_sp_t<ACTV, 2, 2, 2, true>(a, grid, stream);   \
+      else gam_launch_gemm_sp_t<ACTV, 3, 2, 2, true>(a, grid, stream);           \
+    } else switch (mt) {                                                         \
+      case 2: gam_launch_gemm_sp_t<ACTV, 2, 4, 2, true>(a, grid, stream); break; \
+      case 3: gam_launch_gemm_sp_t<ACTV, 3, 4, 2, true>(a, grid, stream); break; \
+      default: gam_launch_gemm_sp_t<ACTV, 4, 4, 2, true>(a, grid, stream); break; \
+    }                                                                            \
+  } else if (ns == 3) {                                                          \
     if (nw == 4) gam_launch_gemm_sp_t<ACTV, 2, 4, 3>(a, grid, stream);           \
     else if (mt == 2) gam_launch_gemm_sp_t<ACTV, 2, 2, 3>(a, grid, stream);      \
     else gam_launch_gemm_sp_t<ACTV, 3, 2, 3>(a, grid, stream);                   \
@@ -594,6 +623,17 @@ __global__ __launch_bounds__(256) void gam_to_sp32_kernel(const float* __restric
     _Float16* p = y + (e >> 5) * 64 + (e & 31);
     *reinterpret_cast<gam_half4*>(p) = h;
     *reinterpret_cast<gam_half4*>(p + 32) = l;
+  }
+}
+
+// fp32 [rows, K] -> plain fp16 rows (format 2 of gam_store4; the one-term mode's operand), row-scaled like gam_to_sp32_kernel
+__global__ __launch_bounds__(256) void gam_to_h16_kernel(const float* __restrict__ x, _Float16* __restrict__ y, size_t n4,
+                                                         const float* __restrict__ rs, int K) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    if (rs != nullptr) v = v * (1.0f / rs[(i * 4) / (size_t)K]);
+    reinterpret_cast<gam_half4*>(y)[i] = __builtin_convertvector(v, gam_half4);
   }
 }
 

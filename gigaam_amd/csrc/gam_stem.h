@@ -40,7 +40,7 @@ struct GamConv1Args {
   const int* len0;     // valid input frames
   const int* len1;     // valid output frames of this stage
   int B, T, F, Ta, FP, C, T1;
-  int img_split;       // channels of a pixel in the sp32 GEMM-operand layout (C % 32 == 0)
+  int img_split;       // 1: channels of a pixel in the sp32 GEMM-operand layout (C % 32 == 0); 2: dense fp16 image (C % 64 == 0)
   int* range_flag;     // img_split: a pixel beyond fp16's range sets it (gam_common.h gam_range_note); may be null
 };
 
@@ -49,10 +49,13 @@ __global__ __launch_bounds__(256) void gam_conv2d1_kernel(GamConv1Args a) {
   const int tid = threadIdx.x;
   const int p = blockIdx.x, b = blockIdx.y;
   const int t1 = p - 1;
-  float* out = a.img + ((size_t)b * 2 * a.Ta + p) * (size_t)a.FP * a.C;
+  // (format 2 of gam_store*: a dense fp16 image -- the row starts at the same ELEMENT offset of the buffer viewed as halfs)
+  const size_t pix0 = ((size_t)b * 2 * a.Ta + p) * (size_t)a.FP * a.C;
+  float* out = a.img_split == 2 ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(a.img) + pix0) : a.img + pix0;
+  const int row_floats = a.img_split == 2 ? a.FP * a.C / 2 : a.FP * a.C;
   const bool live = t1 >= 0 && t1 < a.T1 && t1 < a.len1[b];
   if (!live) {
-    for (int i = tid; i < a.FP * a.C; i += 256) out[i] = 0.f;
+    for (int i = tid; i < row_floats; i += 256) out[i] = 0.f;
     return;
   }
   const int l0 = a.len0[b];
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256) void gam_conv2d1_kernel(GamConv1Args a) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) w[k] = a.w[c * 9 + k];
     const float bias = a.bias[c];
-    out[c] = 0.f;  // q = 0 border
+    gam_store1(out, 0, c, 0.f, a.img_split);  // q = 0 border (zero in every format)
     for (int q = 1; q < a.FP; ++q) {
       const int fb = 2 * (q - 1);  // xin column of kw = 0  (f = 2*f1 - 1 -> index f + 1)
       float acc = bias;

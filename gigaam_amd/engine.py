@@ -132,17 +132,20 @@ class HipEngine:
             pass
 
     def set_gemm_mode(self, mode: str) -> None:
-        """"f32" (exact fp32 MFMA) or "f16x3" (split-fp16 MFMA, fp32-equivalent; default)."""
-        m = {"f32": _lib.GEMM_F32, "f16x3": _lib.GEMM_F16X3}[mode]
+        """"f32" (exact fp32 MFMA), "f16x3" (three-term split-fp16 MFMA, fp32-equivalent; the default) or "f16" (OPT-IN speed
+        mode: one fp16 MFMA per product, fp32 accumulation -- the reference's GPU autocast contract, not its CPU one)."""
+        m = {"f32": _lib.GEMM_F32, "f16x3": _lib.GEMM_F16X3, "f16": _lib.GEMM_F16}[mode]
         self._check(self.lib.gam_set_gemm_mode(self._h, m), "gam_set_gemm_mode")
 
     @property
     def gemm_mode(self) -> str:
-        return {_lib.GEMM_F32: "f32", _lib.GEMM_F16X3: "f16x3"}[self.lib.gam_get_gemm_mode(self._h)]
+        return {_lib.GEMM_F32: "f32", _lib.GEMM_F16X3: "f16x3", _lib.GEMM_F16: "f16"}[self.lib.gam_get_gemm_mode(self._h)]
 
     def range_flag(self) -> bool:
         """True if, since the last call, an unscaled split-fp16 GEMM operand left fp16's range (gam_range_flag);
-        synchronises the current stream and clears the flag."""
+        synchronises the current stream and clears the flag.  NOTE: ``ctc_greedy`` / ``rnnt_greedy`` CONSUME the flag (they
+        move it into the hidden tail word of the counts buffer they return, which ``collect`` reads): after a decode call
+        this method reports 0 -- read the flag from that buffer (shard.range_flag_of) or through ``collect``."""
         out = C.c_int(0)
         with torch.cuda.device(self.device):
             self._check(self.lib.gam_range_flag(self._h, C.byref(out), self._stream()), "gam_range_flag")

@@ -103,16 +103,24 @@ class GigaAM(nn.Module):
         features, feature_lengths = self.preprocessor(features, feature_lengths)
         out = self.encoder(features, feature_lengths)
         eng = getattr(self.encoder, "engine", None)
-        if self._check_range and eng is not None and eng.gemm_mode == "f16x3" and eng.range_flag():
+        if self._check_range and eng is not None and eng.gemm_mode != "f32" and eng.range_flag():
             # an activation outside fp16's range reached a split-fp16 GEMM operand (include/gigaam_hip.h,
             # gam_range_flag): the batch is repeated on the exact-fp32 MFMA path, which has no such limit
             self._warn_range("this batch was")
+            mode = eng.gemm_mode
             eng.set_gemm_mode("f32")
             try:
                 out = self.encoder(features, feature_lengths)
             finally:
-                eng.set_gemm_mode("f16x3")
+                eng.set_gemm_mode(mode)
         return out
+
+    def set_arithmetic(self, mode: str) -> None:
+        """Arithmetic of the dense contractions (include/gigaam_hip.h, gam_set_gemm_mode): "f16x3" -- the default, a
+        three-term fp16 split with fp32 accumulation, fp32-equivalent (what every parity claim of this package is made in);
+        "f32" -- exact fp32 MFMA; "f16" -- OPT-IN speed mode, one fp16 MFMA per product: the contract of the reference's
+        own GPU default (fp16 autocast, gigaam/model.py:34-37), not of its CPU path.  Not part of the reference's API."""
+        self.encoder.engine.set_gemm_mode(mode)
 
     @staticmethod
     def _warn_range(what: str) -> None:
@@ -136,11 +144,12 @@ class GigaAM(nn.Module):
         except RangeOverflow:
             eng = self.encoder.engine
             self._warn_range(what)
+            mode = eng.gemm_mode
             eng.set_gemm_mode("f32")
             try:
                 return fn()
             finally:
-                eng.set_gemm_mode("f16x3")
+                eng.set_gemm_mode(mode)
 
     @property
     def _device(self) -> torch.device:
@@ -171,13 +180,14 @@ class GigaAM(nn.Module):
         """``_encode`` + the blocking range check of ``forward`` (for heads that bring no counts to the host)."""
         out = self._encode(wav, lengths)
         eng = self.encoder.engine
-        if self._check_range and eng.gemm_mode == "f16x3" and eng.range_flag():
+        if self._check_range and eng.gemm_mode != "f32" and eng.range_flag():
             self._warn_range("this batch was")
+            mode = eng.gemm_mode
             eng.set_gemm_mode("f32")
             try:
                 out = self._encode(wav, lengths)
             finally:
-                eng.set_gemm_mode("f16x3")
+                eng.set_gemm_mode(mode)
         return out
 
 
@@ -325,6 +335,6 @@ class GigaAMASR(GigaAM):
             return result
 
         eng = getattr(self.encoder, "_engine", None)
-        if eng is not None and eng.gemm_mode == "f16x3":
+        if eng is not None and eng.gemm_mode != "f32":
             eng.range_flag()     # a flag left behind by earlier direct engine use must not cost this file an fp32 rerun
         return LongformTranscriptionResult(segments=self._with_f32_fallback(run, "the file was"))

@@ -123,11 +123,17 @@ int gam_emo_probs(gam_handle* h, const float* encoded, const int32_t* enc_len, i
  *   GAM_GEMM_F16X3 -- three-term split on v_mfma_f32_32x32x16_f16 with fp32 accumulation
  *                     (a = a_hi + a_lo, w = w_hi + w_lo; the a_lo.w_lo term, ~2^-22 relative,
  *                     is dropped): fp32-equivalent accuracy at several times the rate.
- * Default: GAM_GEMM_F16X3 (environment GAM_GEMM_MODE=f32 selects the other at gam_create).
- * The CTC / RNN-T head GEMMs always use GAM_GEMM_F32; gam_op_gemm follows the mode. */
-enum { GAM_GEMM_F32 = 0, GAM_GEMM_F16X3 = 1 };
+ *   GAM_GEMM_F16   -- OPT-IN speed mode (r04), never the default: ONE fp16 MFMA per product on the hi planes of the same
+ *                     operands (a ~ a_hi, w ~ w_hi: 11 significant bits each), fp32 accumulation, fp32 softmax /
+ *                     LayerNorm / residual stream -- the arithmetic contract of the reference's own GPU default (fp16
+ *                     autocast + half() encoder, gigaam/model.py:34-37, gigaam/__init__.py:188-189), NOT that of its CPU
+ *                     path: results differ from GAM_GEMM_F16X3 at the 1e-3 .. 1e-2 level in the encoder output.  Covers
+ *                     the encoder GEMMs, the stem convolution and the attention products; the range guard below applies.
+ * Default: GAM_GEMM_F16X3 (environment GAM_GEMM_MODE=f32 | f16 selects another at gam_create).
+ * The CTC / RNN-T head GEMMs and the windowed DFT always use GAM_GEMM_F32; gam_op_gemm follows the mode. */
+enum { GAM_GEMM_F32 = 0, GAM_GEMM_F16X3 = 1, GAM_GEMM_F16 = 2 };
 int gam_set_gemm_mode(gam_handle* h, int mode);
-/* Range guard of GAM_GEMM_F16X3.  LayerNorm-produced operands carry a per-row power-of-two scale and cannot leave
+/* Range guard of GAM_GEMM_F16X3 / GAM_GEMM_F16.  LayerNorm-produced operands carry a per-row power-of-two scale and cannot leave
  * fp16's range; the other split-fp16 operands (FFN hidden, conv-module output, stem image and Conv2d#2 output, and the
  * attention's q / k / v -- its context is a convex combination of v) are split as they are, and a value beyond +-60000
  * there sets a device flag instead of silently becoming inf.  gam_range_flag copies the flag

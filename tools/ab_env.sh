@@ -4,7 +4,7 @@ TAG=$1; VAR=$2; shift 2
 VALS=(); while [[ $# -gt 0 && $1 != "--" ]]; do VALS+=("$1"); shift; done; [[ $1 == "--" ]] && shift
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-C="--steps 20 --warmup 5 --no-f32-leg --no-h2d-leg --cpu-utts 0 $*"
+C="--steps 20 --warmup 5 --no-f32-leg --no-h2d-leg --no-f16-leg --cpu-utts 0 $*"
 for rep in 1 2; do
   for i in "${!VALS[@]}"; do
     v=${VALS[$i]}

@@ -5,7 +5,7 @@ TAG=$1; shift
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
-C="--steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-power --cpu-utts 0 --no-profile"
+C="--steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power --cpu-utts 0 --no-profile"
 one() {  # name lib args
   local name=$1 lib=$2; shift 2
   ( GIGAAM_HIP_LIB=$lib timeout 300 python bench.py "$@" $C ) 2> $OUT/$name.err | grep -a '^{' > $OUT/$name.json

@@ -5,6 +5,6 @@ import json,sys; d=json.loads(open('$OUT/$name.json').read()); print('$name', d[
 for i in 0 1; do
   lib=gigaam_amd/libgigaam_hip_old.so; [ $i = 1 ] && lib=gigaam_amd/libgigaam_hip.so
   one c1_$i $lib --config 1 --steps 50 --warmup 10 --no-profile
-  one b4_$i $lib --batch 4 --steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-power --no-profile
-  one head_$i $lib --steps 20 --warmup 5 --no-f32-leg --no-h2d-leg --no-power
+  one b4_$i $lib --batch 4 --steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power --no-profile
+  one head_$i $lib --steps 20 --warmup 5 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power
 done

@@ -17,10 +17,10 @@ i=0
 for lib in "$@"; do
   for rep in 1 2; do
     one c1_${i}_$rep $lib --config 1 --steps 50 --warmup 10 --no-profile
-    one b4_${i}_$rep $lib --batch 4 --steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-power --no-profile
+    one b4_${i}_$rep $lib --batch 4 --steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power --no-profile
   done
-  one b8_$i $lib --batch 8 --steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-power --no-profile
-  one b4prof_$i $lib --batch 4 --steps 20 --warmup 5 --no-f32-leg --no-h2d-leg --no-power
-  one head_$i $lib --steps 20 --warmup 5 --no-f32-leg --no-h2d-leg
+  one b8_$i $lib --batch 8 --steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power --no-profile
+  one b4prof_$i $lib --batch 4 --steps 20 --warmup 5 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power
+  one head_$i $lib --steps 20 --warmup 5 --no-f32-leg --no-h2d-leg --no-f16-leg
   i=$((i+1))
 done

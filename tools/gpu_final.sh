@@ -15,15 +15,15 @@ rm -f $GAM_TEST_REPORT
 ( time timeout 1200 python -m pytest tests -q -m gpu ) > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
 ( timeout 300 python __graft_entry__.py --smoke ) > $OUT/smoke.log 2>&1; echo "smoke rc=$?"
 ( timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench.log 2> $OUT/bench.err; echo "bench rc=$?"
-( timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --cpu-utts 0 --no-f32-leg --no-h2d-leg ) > $OUT/bench_torchrun1.log 2>&1; echo "torchrun rc=$?"
+( timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 5 --warmup 2 --cpu-utts 0 --no-f32-leg --no-h2d-leg --no-f16-leg ) > $OUT/bench_torchrun1.log 2>&1; echo "torchrun rc=$?"
 cd /tmp
-B="python $R/bench.py --steps 1 --warmup 1 --cpu-utts 0 --no-profile --no-f32-leg --no-h2d-leg"
-( timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_trace -o b -- python $R/bench.py --steps 5 --warmup 2 --cpu-utts 0 --no-f32-leg --no-h2d-leg ) > $OUT/pf_trace.log 2>&1
+B="python $R/bench.py --steps 1 --warmup 1 --cpu-utts 0 --no-profile --no-f32-leg --no-h2d-leg --no-f16-leg"
+( timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_trace -o b -- python $R/bench.py --steps 5 --warmup 2 --cpu-utts 0 --no-f32-leg --no-h2d-leg --no-f16-leg ) > $OUT/pf_trace.log 2>&1
 ( timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pf_fetch -o b -- $B ) > $OUT/pf_fetch.log 2>&1
 ( timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pf_write -o b -- $B ) > $OUT/pf_write.log 2>&1
 ( timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pf_sq -o b -- $B ) > $OUT/pf_sq.log 2>&1
-( timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_trace_c3 -o b -- python $R/bench.py --config 3 --steps 3 --warmup 1 --cpu-utts 0 --no-f32-leg --no-h2d-leg ) > $OUT/pf_trace_c3.log 2>&1
-( timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_trace_b4 -o b -- python $R/bench.py --batch 4 --steps 10 --warmup 3 --cpu-utts 0 --no-f32-leg --no-h2d-leg --no-power --no-profile ) > $OUT/pf_trace_b4.log 2>&1
+( timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_trace_c3 -o b -- python $R/bench.py --config 3 --steps 3 --warmup 1 --cpu-utts 0 --no-f32-leg --no-h2d-leg --no-f16-leg ) > $OUT/pf_trace_c3.log 2>&1
+( timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_trace_b4 -o b -- python $R/bench.py --batch 4 --steps 10 --warmup 3 --cpu-utts 0 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power --no-profile ) > $OUT/pf_trace_b4.log 2>&1
 ( timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_trace_c1 -o b -- python $R/bench.py --config 1 --steps 10 --warmup 3 --cpu-utts 0 --no-profile ) > $OUT/pf_trace_c1.log 2>&1
 cd $R
 for n in trace fetch write sq trace_c3 trace_b4 trace_c1; do

@@ -23,7 +23,7 @@ if [[ $WHAT == all || $WHAT == *configs* ]]; then
 fi
 if [[ $WHAT == all || $WHAT == *prof* ]]; then
   cd /tmp && export TMPDIR=/tmp
-  timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --cpu-utts 0 --no-f32-leg --no-h2d-leg > $GRAFT_REPO_ROOT/$OUT/prof_bench.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --cpu-utts 0 --no-f32-leg --no-h2d-leg --no-f16-leg > $GRAFT_REPO_ROOT/$OUT/prof_bench.log 2>&1
   echo "rocprof rc=$?" | tee -a $GRAFT_REPO_ROOT/$OUT/summary.txt
   cd $GRAFT_REPO_ROOT
   DB=$(find $OUT/prof -name "*.db" | head -1)

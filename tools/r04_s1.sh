@@ -9,7 +9,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-C="--steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-power --cpu-utts 0 --no-profile"
+C="--steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power --cpu-utts 0 --no-profile"
 one() {  # name env... -- args
   local name=$1; shift
   local envs=(); while [[ $# -gt 0 && $1 != "--" ]]; do envs+=("$1"); shift; done; shift
@@ -40,7 +40,7 @@ one b32_default X=1 -- --batch 32
 cd /tmp
 for v in default nocapture; do
   E="X=1"; [[ $v == nocapture ]] && E="DEBUG_CLR_GRAPH_PACKET_CAPTURE=0"
-  ( env $E timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_b4_$v -o b -- python $R/bench.py --batch 4 --steps 10 --warmup 3 --cpu-utts 0 --no-f32-leg --no-h2d-leg --no-power --no-profile ) > $OUT/pf_b4_$v.log 2>&1
+  ( env $E timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_b4_$v -o b -- python $R/bench.py --batch 4 --steps 10 --warmup 3 --cpu-utts 0 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power --no-profile ) > $OUT/pf_b4_$v.log 2>&1
   DB=$(find $OUT/pf_b4_$v -name "*.db" | head -1)
   [ -n "$DB" ] && python $R/tools/rocpd_summary.py $DB $OUT/trace_b4_${v}_summary.txt "rocprofv3 kernel trace, bench.py --batch 4 ($v)" > /dev/null 2>&1
   grep -a "copyBuffer\|fillBuffer" $OUT/trace_b4_${v}_summary.txt | cut -c1-160

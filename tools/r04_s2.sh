@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 export GAM_TEST_REPORT=$OUT/measured_errors.jsonl
 ( time timeout 1200 python -m pytest tests -q -x -m gpu ) > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $OUT/pytest_gpu.log
-C="--steps 10 --warmup 3 --cpu-utts 0 --no-f32-leg --no-h2d-leg --no-power --no-profile"
+C="--steps 10 --warmup 3 --cpu-utts 0 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power --no-profile"
 ( GAM_GRAPH_DEBUG=1 timeout 300 python bench.py --batch 4 $C ) > $OUT/b4_graphdebug.log 2>&1; grep -a "graph replays" $OUT/b4_graphdebug.log
 cd /tmp
 for v in default nograph; do

@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 ( GAM_SP_STAGES=3 timeout 900 python -m pytest tests/test_hip_parity.py -q -x -m gpu -k "gemm_kernel or encoder_matches or ctc_bit_exact or fused_splitk or graph_replay" ) > $OUT/pytest_ns3.log 2>&1; echo "pytest(ns3) rc=$?"; tail -3 $OUT/pytest_ns3.log
 ( timeout 300 python -m pytest tests/test_hip_hardening.py -q -x -m gpu ) > $OUT/pytest_hardening.log 2>&1; echo "pytest(hardening) rc=$?"; tail -3 $OUT/pytest_hardening.log
-C="--steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-power --cpu-utts 0 --no-profile"
+C="--steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power --cpu-utts 0 --no-profile"
 one() {  # name env -- args
   local name=$1 e=$2; shift 3
   ( env $e timeout 300 python bench.py "$@" $C ) 2> $OUT/$name.err | grep -a '^{' > $OUT/$name.json

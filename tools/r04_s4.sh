@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 export GAM_TEST_REPORT=$OUT/measured_errors.jsonl
 ( time timeout 1200 python -m pytest tests -q -x -m gpu ) > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; grep -a "passed\|failed" $OUT/pytest_gpu.log | tail -2
-C="--steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-power --cpu-utts 0 --no-profile"
+C="--steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power --cpu-utts 0 --no-profile"
 one() {  # name env args
   local name=$1 e=$2; shift 2
   ( env $e timeout 300 python bench.py "$@" $C ) 2> $OUT/$name.err | grep -a '^{' > $OUT/$name.json
@@ -30,7 +30,7 @@ for rep in 1 2; do
   done
 done
 cd /tmp
-( timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_b4 -o b -- python $R/bench.py --batch 4 --steps 10 --warmup 3 --cpu-utts 0 --no-f32-leg --no-h2d-leg --no-power --no-profile ) > $OUT/pf_b4.log 2>&1
+( timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_b4 -o b -- python $R/bench.py --batch 4 --steps 10 --warmup 3 --cpu-utts 0 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power --no-profile ) > $OUT/pf_b4.log 2>&1
 DB=$(find $OUT/pf_b4 -name "*.db" | head -1)
 [ -n "$DB" ] && python $R/tools/rocpd_summary.py $DB $OUT/trace_b4_summary.txt "rocprofv3 kernel trace, bench.py --batch 4 (r04: planned stages, thread-per-frame CTC kernel)" > /dev/null 2>&1
 find $OUT -name "*.db" -delete

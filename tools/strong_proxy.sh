@@ -6,7 +6,7 @@
 TAG=${1:-strong_proxy}
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 OUT=gpurun_out/$TAG; mkdir -p $OUT
-C="--steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-power --cpu-utts 0"
+C="--steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power --cpu-utts 0"
 rm -f $OUT/strong_proxy.jsonl
 for b in 32 16 8 4 2; do
   ( timeout 300 python bench.py --batch $b $C --no-profile ) 2> $OUT/b$b.err | grep -a '^{' > $OUT/b$b.json
@@ -16,7 +16,7 @@ import json, sys
 d = json.loads(open(sys.argv[1]).read()); p = json.loads(open(sys.argv[2]).read())
 rec = {"utterances_per_rank": d["config"]["global_batch"], "ms_per_step": d["ms_per_step"], "rtfx": d["value"],
        "ms_per_step_with_per_launch_events": p["ms_per_step"], "kernel_classes_ms_per_step": p.get("kernel_classes_ms_per_step"),
-       "command": "bench.py --batch N --steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-power --cpu-utts 0 --no-profile"}
+       "command": "bench.py --batch N --steps 30 --warmup 8 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power --cpu-utts 0 --no-profile"}
 open(sys.argv[3], "a").write(json.dumps(rec) + "\n")
 print("batch", rec["utterances_per_rank"], rec["ms_per_step"], "ms (with events:", rec["ms_per_step_with_per_launch_events"], ")", rec["kernel_classes_ms_per_step"])
 PY
