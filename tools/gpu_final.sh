@@ -3,7 +3,7 @@
 # torchrun launch of the distributed path, rocprofv3 kernel trace + PMC passes (separate runs, as the guide
 # prescribes), all five BASELINE configurations, the strong-scaling proxies and the shared-device rehearsal of the
 # multi-rank program.  Everything lands under gpurun_out/$TAG/.
-#   gpurun --timeout 2400 -- 'bash tools/gpu_final.sh r03_final'
+#   gpurun --timeout 2400 -- 'bash tools/gpu_final.sh r04_final'
 TAG=${1:-final}
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD
@@ -33,7 +33,9 @@ done
 FD=$(find $OUT/pf_fetch -name "*.db" | head -1); WD=$(find $OUT/pf_write -name "*.db" | head -1)
 [ -n "$FD" ] && [ -n "$WD" ] && python tools/pmc_traffic.py $FD $WD $OUT/pmc_traffic_f16x3.json > $OUT/pmc_traffic.log 2>&1
 find $OUT -name "*.db" -delete
+python tools/hbm_kernels.py $OUT/trace_summary.txt $OUT/fetch_summary.txt $OUT/write_summary.txt > $OUT/hbm_kernels.txt 2> $OUT/hbm_kernels.err
 ( timeout 900 python tools/bench_configs.py --only 1,3,4,5 --out $OUT/configs.jsonl ) > $OUT/configs.log 2>&1; echo "configs rc=$?"
+( timeout 600 python tools/published_shapes.py --out $OUT/published_shapes.jsonl ) > $OUT/published.log 2>&1; echo "published rc=$?"
 # strong-scaling proxies: the per-rank workloads of the 1/2/4/8/16-GPU strong points of config 2 on ONE GPU
 bash tools/strong_proxy.sh $TAG > $OUT/strong_proxy.log 2>&1; cat $OUT/strong_proxy.log
 # the multi-rank program on this 1-GPU box: plain --gpus 2 must refuse clearly; --oversubscribe runs it over gloo
@@ -41,6 +43,7 @@ bash tools/strong_proxy.sh $TAG > $OUT/strong_proxy.log 2>&1; cat $OUT/strong_pr
 for sc in weak strong; do
   ( timeout 300 python bench.py --gpus 2 --oversubscribe --scaling $sc --steps 5 --warmup 2 --no-profile --cpu-utts 0 ) 2> $OUT/rehearsal_$sc.err | grep -a '^{' > $OUT/rehearsal_gpus2_$sc.json; echo "rehearsal $sc rc=$?"
 done
+( timeout 300 python bench.py --gpus 2 --oversubscribe --config 5 --steps 1 --warmup 1 --no-profile --cpu-utts 0 ) 2> $OUT/rehearsal_c5.err | grep -a '^{' > $OUT/rehearsal_gpus2_config5.json; echo "rehearsal config5 x2 rc=$?"
 ( timeout 300 python bench.py --gpus 4 --oversubscribe --config 4 --utts-per-gpu 32 --steps 1 --warmup 1 --no-profile ) 2> $OUT/rehearsal_c4.err | grep -a '^{' > $OUT/rehearsal_gpus4_config4.json; echo "rehearsal config4 x4 rc=$?"
 tail -3 $OUT/pytest_gpu.log; tail -1 $OUT/smoke.log
 grep -a "^{" $OUT/bench.log | cut -c1-400
