@@ -1010,7 +1010,9 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       a.img_split = (sp && C % 32 == 0) ? spf : 0;
       a.range_flag = h->use_range ? h->range_flag : nullptr;
       ProfScope ps(h, s, GAM_PF_STEM, (double)B * 2 * Ta * FP * C * 4.0);
-      hipLaunchKernelGGL(gam_conv2d1_kernel, dim3(2 * Ta, B), dim3(256), 0, s, a);
+      if (a.img_split == 2) hipLaunchKernelGGL(gam_conv2d1_kernel<2>, dim3(2 * Ta, B), dim3(256), 0, s, a);
+      else if (a.img_split == 1) hipLaunchKernelGGL(gam_conv2d1_kernel<1>, dim3(2 * Ta, B), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(gam_conv2d1_kernel<0>, dim3(2 * Ta, B), dim3(256), 0, s, a);
       HIPCHK(h, hipGetLastError());
       // two slack rows past the last utterance (read by its padding frame only)
       // two slack rows past the last utterance (read by its padding frame only); the dense fp16 image ends at half the offset

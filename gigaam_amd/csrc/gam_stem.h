@@ -44,6 +44,9 @@ struct GamConv1Args {
   int* range_flag;     // img_split: a pixel beyond fp16's range sets it (gam_common.h gam_range_note); may be null
 };
 
+// FMT = a.img_split as a compile-time constant: the per-element store of this write-bound kernel takes no format branch
+// (with the run-time flag and its third case the kernel went from 588 to 643 us at 32 x 20 s)
+template <int FMT>
 __global__ __launch_bounds__(256) void gam_conv2d1_kernel(GamConv1Args a) {
   __shared__ float xin[3][132];   // f = -1 .. F (F <= 128)
   const int tid = threadIdx.x;
@@ -51,8 +54,8 @@ __global__ __launch_bounds__(256) void gam_conv2d1_kernel(GamConv1Args a) {
   const int t1 = p - 1;
   // (format 2 of gam_store*: a dense fp16 image -- the row starts at the same ELEMENT offset of the buffer viewed as halfs)
   const size_t pix0 = ((size_t)b * 2 * a.Ta + p) * (size_t)a.FP * a.C;
-  float* out = a.img_split == 2 ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(a.img) + pix0) : a.img + pix0;
-  const int row_floats = a.img_split == 2 ? a.FP * a.C / 2 : a.FP * a.C;
+  float* out = FMT == 2 ? reinterpret_cast<float*>(reinterpret_cast<_Float16*>(a.img) + pix0) : a.img + pix0;
+  const int row_floats = FMT == 2 ? a.FP * a.C / 2 : a.FP * a.C;
   const bool live = t1 >= 0 && t1 < a.T1 && t1 < a.len1[b];
   if (!live) {
     for (int i = tid; i < row_floats; i += 256) out[i] = 0.f;
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256) void gam_conv2d1_kernel(GamConv1Args a) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) w[k] = a.w[c * 9 + k];
     const float bias = a.bias[c];
-    gam_store1(out, 0, c, 0.f, a.img_split);  // q = 0 border (zero in every format)
+    gam_store1(out, 0, c, 0.f, FMT);  // q = 0 border (zero in every format)
     for (int q = 1; q < a.FP; ++q) {
       const int fb = 2 * (q - 1);  // xin column of kw = 0  (f = 2*f1 - 1 -> index f + 1)
       float acc = bias;
@@ -81,8 +84,8 @@ __global__ __launch_bounds__(256) void gam_conv2d1_kernel(GamConv1Args a) {
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) acc = fmaf(w[kh * 3 + kw], xin[kh][fb + kw], acc);
       acc = fmaxf(acc, 0.f);
-      if (a.img_split) gam_range_note(a.range_flag, acc, 0.f, 0.f, 0.f);   // the stored (post-ReLU) image feeds Conv2d#2 unscaled
-      gam_store1(out, (size_t)q * a.C, c, acc, a.img_split);
+      if (FMT != 0) gam_range_note(a.range_flag, acc, 0.f, 0.f, 0.f);   // the stored (post-ReLU) image feeds Conv2d#2 unscaled
+      gam_store1(out, (size_t)q * a.C, c, acc, FMT);
     }
   }
 }
