@@ -670,6 +670,7 @@ def main():
         barrier_sync()
         t_feed = (time.perf_counter() - t0) / n_b
         h2d_leg = {"ms_per_step_serial_copy": round(t_serial * 1e3, 3), "ms_per_step_feeder": round(t_feed * 1e3, 3), "steps": k_h,
+                   "feeder_host_collate_ms_per_batch": round(fd.collate_seconds / max(1, fd.batches_staged) * 1e3, 3),
                    "h2d_bytes_per_step": int(wav_h.numel() * 4),
                    "note": "waveform starts in host memory; serial = pinned->device copy on the launch stream before every step; "
                            "feeder = gigaam_amd.feeder.BatchFeeder (batch collated into a pinned staging buffer, side-stream copy "

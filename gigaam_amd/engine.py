@@ -159,9 +159,28 @@ class HipEngine:
         counts._gam_ext = ext          # (plain attribute: keeps the buffer alive and findable from the view)
         return counts, ext
 
-    def _fetch_flag(self, ext: Tensor) -> None:
+    def _fetch_flag(self, ext: Tensor, counts: Optional[Tensor] = None) -> None:
         rc = self.lib.gam_range_flag_fetch(self._h, C.c_void_p(ext.data_ptr() + 4 * (ext.numel() - 1)), self._stream())
         self._check(rc, "gam_range_flag_fetch")
+        if counts is not None:
+            # "this decode is complete" on the launch stream: ``collect`` waits for THIS on a side stream, so a caller that has
+            # already launched the next batch (the one-batch pipelines of model.transcribe_longform, shard.run_sharded,
+            # bench.py configs 4 / 5) is not held until that next batch has finished too -- a ``.cpu()`` on the launch
+            # stream is ordered behind everything enqueued there, which made the "launch n, then collect n-1" pipelines wait
+            # for batch n and left the GPU idle while the host staged batch n+1 (measured: +3.9 ms per 33 ms step)
+            evt = torch.cuda.Event()
+            evt.record(torch.cuda.current_stream(self.device))
+            counts._gam_evt = evt
+
+    _collect_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+    @classmethod
+    def _collect_stream(cls, device: torch.device) -> "torch.cuda.Stream":
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        st = cls._collect_streams.get(key)
+        if st is None:
+            st = cls._collect_streams[key] = torch.cuda.Stream(device)
+        return st
 
     @staticmethod
     def collect(ids: Tensor, frames: Tensor, counts: Tensor):
@@ -169,12 +188,25 @@ class HipEngine:
         split-fp16 range flag accumulated up to this decode (when ``counts`` came from ctc_greedy / rnnt_greedy), one
         for the used part of ids/frames."""
         ext = getattr(counts, "_gam_ext", None)
-        n = (ext if ext is not None else counts).cpu().tolist()
-        flag = bool(n.pop()) if ext is not None else False
+        evt = getattr(counts, "_gam_evt", None)
+        if evt is not None and ids.is_cuda:
+            # the copies run on a side stream that waits for the decode's own completion event only (see _fetch_flag)
+            side = HipEngine._collect_stream(ids.device)
+            with torch.cuda.stream(side):
+                side.wait_event(evt)
+                n = (ext if ext is not None else counts).cpu().tolist()
+                flag = bool(n.pop()) if ext is not None else False
+                width = max(n) if n else 0
+                ids_h, fr_h = ids[:, :width].cpu(), frames[:, :width].cpu()
+            for t in (ids, frames, ext if ext is not None else counts):
+                t.record_stream(side)
+        else:
+            n = (ext if ext is not None else counts).cpu().tolist()
+            flag = bool(n.pop()) if ext is not None else False
+            width = max(n) if n else 0
+            ids_h, fr_h = ids[:, :width].cpu(), frames[:, :width].cpu()
         if n and min(n) < 0:   # cannot happen: gam_rnnt_greedy repairs failed clusters itself (gam_api.hip launch_single)
             raise GigaAMHipError("RNN-T decode left an utterance undecoded (counts = -1)")
-        width = max(n) if n else 0
-        ids_h, fr_h = ids[:, :width].cpu(), frames[:, :width].cpu()
         return [(ids_h[i, :c].tolist(), fr_h[i, :c].tolist()) for i, c in enumerate(n)], flag
 
     def feat_frames(self, n_samples: int) -> int:
@@ -247,7 +279,7 @@ class HipEngine:
             rc = self.lib.gam_ctc_greedy(self._h, _ptr(encoded), _ptr(enc_len), b, tp, _ptr(ids), _ptr(frames),
                                          _ptr(counts), self._stream())
             self._check(rc, "gam_ctc_greedy")
-            self._fetch_flag(ext)
+            self._fetch_flag(ext, counts)
         return ids, frames, counts
 
     def rnnt_greedy(self, encoded: Tensor, enc_len: Tensor, max_symbols: int, dump_cap: int = 0):
@@ -266,7 +298,7 @@ class HipEngine:
             rc = self.lib.gam_rnnt_greedy(self._h, _ptr(encoded), _ptr(enc_len), b, tp, max_symbols, _ptr(ids),
                                           _ptr(frames), _ptr(counts), _ptr(dump), _ptr(dcount), dump_cap, self._stream())
             self._check(rc, "gam_rnnt_greedy")
-            self._fetch_flag(ext)
+            self._fetch_flag(ext, counts)
         if dump_cap > 0:
             return ids, frames, counts, dump, dcount
         return ids, frames, counts

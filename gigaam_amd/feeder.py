@@ -33,11 +33,12 @@ def collate(segments: Sequence[Tensor], out: Tensor = None) -> Tuple[Tensor, Ten
     # OpenMP thread of the host, and on a box with a CPU quota those spinning threads get the whole process throttled
     # for tens of milliseconds -- seen as 50 ms holes in the middle of a batch's kernel launches (profiles/r02_config5_*)
     hb = batch.numpy()
-    if out is not None:
-        hb.fill(0)
     for j, c in enumerate(segments):
         src = c.reshape(-1)
-        hb[j, : src.shape[0]] = src.numpy() if src.device.type == "cpu" and not src.requires_grad else src.detach().cpu().numpy()
+        n = src.shape[0]
+        hb[j, :n] = src.numpy() if src.device.type == "cpu" and not src.requires_grad else src.detach().cpu().numpy()
+        if out is not None and n < lmax:
+            hb[j, n:] = 0          # only the padding tail of a reused staging buffer is cleared (every byte is written once)
     return batch, lens
 
 
@@ -67,6 +68,7 @@ class BatchFeeder:
         self._pin = [torch.empty((max_b * max_l,), dtype=torch.float32).pin_memory() for _ in range(2)]
         self._pin_len = [torch.empty((max_b,), dtype=torch.int64).pin_memory() for _ in range(2)]
         self._dev = [torch.empty((max_b * max_l,), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.collate_seconds, self.batches_staged = 0.0, 0     # host time spent assembling batches (bench.py reports it)
         self._ready = [None, None]      # H2D completion event of the copy last issued from pinned slot i
         self._consumed = [None, None]   # recorded on the consumer's stream once it has enqueued the readers of device slot i
 
@@ -74,7 +76,11 @@ class BatchFeeder:
         b = len(chunk)
         if self._ready[slot] is not None:       # the copy issued two batches ago must have left this pinned buffer
             self._ready[slot].synchronize()
+        import time
+        t0 = time.perf_counter()
         host, lens = collate(chunk, out=self._pin[slot])      # contiguous pinned view of exactly this batch
+        self.collate_seconds += time.perf_counter() - t0
+        self.batches_staged += 1
         lmax = host.shape[1]
         self._pin_len[slot][:b] = lens
         with torch.cuda.stream(self._copy_stream):

@@ -232,7 +232,16 @@ class GigaAMASR(GigaAM):
             return [(text, None) for text, _, _ in decoded]
         from .timestamps_utils import compute_frame_shift, frames_to_words
 
-        wl, el = wav_lens.cpu().tolist(), encoded_len.cpu().tolist()
+        if encoded_len.is_cuda:
+            # on the collect stream, which has already waited for this batch's decode (engine.HipEngine.collect): a copy on
+            # the launch stream would queue behind the NEXT batch's kernels in the one-batch pipelines
+            side = HipEngine._collect_stream(encoded_len.device)
+            with torch.cuda.stream(side):
+                wl, el = wav_lens.cpu().tolist(), encoded_len.cpu().tolist()
+            wav_lens.record_stream(side)
+            encoded_len.record_stream(side)
+        else:
+            wl, el = wav_lens.cpu().tolist(), encoded_len.cpu().tolist()
         out: List[Tuple[str, Optional[List[Word]]]] = []
         for i, (text, ids, frames) in enumerate(decoded):
             shift = compute_frame_shift(int(wl[i]), int(el[i]))
