@@ -1126,7 +1126,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       at.pbuf = rel ? h->pbuf.p : nullptr; at.pos_u = L.pos_u; at.pos_v = L.pos_v; at.ldp = D;
       {
         ProfScope ps(h, s, GAM_PF_ATTN, 4.0 * (double)B * H * (double)Tv * Tv * dk);
-        hipError_t e = gam_launch_attn_mode(at, dk, split_mode(h), s, h->gemm_mode == GAM_GEMM_F16 ? 1 : 3);
+        hipError_t e = gam_launch_attn_mode(at, dk, split_mode(h), s, h->gemm_mode == GAM_GEMM_F16 ? 1 : 3, h->ncu);
         if (e != hipSuccess) return fail(h, -2, "attention launch: %s", hipGetErrorString(e));
       }
       GamGemmArgs go = gemm_args(h->ctx.p, D, L.wo, L.bo, h->x.p, D, N, D, D);
@@ -1490,7 +1490,7 @@ int gam_op_attention(gam_handle* h, const float* q, const float* k, const float*
   at.q = q; at.k = k; at.v = v; at.ctx = ctx; at.lens = lens;
   at.B = B; at.Ta = T; at.Tv = T; at.H = H; at.ldq = D; at.ldv = D; at.ldo = D;
   at.scale = 1.0f / sqrtf((float)GAM_ATT_DK);
-  hipError_t e = gam_launch_attn_mode(at, GAM_ATT_DK, split_mode(h), (hipStream_t)stream, h->gemm_mode == GAM_GEMM_F16 ? 1 : 3);
+  hipError_t e = gam_launch_attn_mode(at, GAM_ATT_DK, split_mode(h), (hipStream_t)stream, h->gemm_mode == GAM_GEMM_F16 ? 1 : 3, h->ncu);
   if (e != hipSuccess) return fail(h, -2, "attention launch: %s", hipGetErrorString(e));
   return 0;
 }

@@ -34,15 +34,16 @@ __device__ __forceinline__ void gam_split8(const float (&v)[8], gam_half8& hi, g
 // tile as G[m][query] = P(rlo + m).(q + v) for the 80 relative positions the (16 queries x 64 keys)
 // block touches -- same three-term split, P rows split on the fly -- and skewed into S^T through LDS.
 #ifndef GAM_ATT_NJ
-#define GAM_ATT_NJ 2   // 16-query sub-blocks per wave (A/B switch: 1 = 64 queries per workgroup, twice the waves per SIMD)
+#define GAM_ATT_NJ 2   // 16-query sub-blocks per wave at large grids (r02 A/B: 1 = 64 queries per workgroup was 192 vs 148 us at 32 x 20 s)
 #endif
+// NJ is a template parameter since r04: small grids (a few utterances per GPU) take NJ = 1 -- 64 queries per workgroup, twice the
+// workgroups -- when 128-query workgroups would leave the chip under one workgroup per CU (gam_launch_attn_mode).
 // TERMS = 3: the three-term split above (fp32-equivalent).  TERMS = 1 (GAM_GEMM_F16, the opt-in speed mode): hi planes only --
 // K, V, Q and P are rounded to fp16 once, one MFMA per product, fp32 accumulation and fp32 softmax statistics: the arithmetic of
 // an fp16 flash attention (the reference's GPU default runs SDPA under fp16 autocast, /root/reference/gigaam/model.py:34-37).
 // The lo planes are neither computed nor stored (the compiler drops the dead halves of the splits).
-template <bool REL, int TERMS = 3>
-__global__ __launch_bounds__(256, GAM_ATT_NJ == 1 ? 4 : 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
-  constexpr int NJ = GAM_ATT_NJ;
+template <bool REL, int TERMS = 3, int NJ = GAM_ATT_NJ>
+__global__ __launch_bounds__(256, NJ == 1 ? (REL ? 3 : 4) : 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
   constexpr bool LO = TERMS == 3;
   a.scale *= 1.44269504088896341f;   // softmax via 2^x: p = 2^(s*log2e - m)
   __shared__ float Gs[REL ? 4 * 80 * 17 : 1];   // per wave: (q+v).P for 80 relative positions x 16 queries
@@ -368,16 +369,23 @@ __global__ __launch_bounds__(256, GAM_ATT_NJ == 1 ? 4 : 2) void gam_attn_f16x3_k
 
 // split = true: fp16-split MFMA path; false: exact-fp32 MFMA path (gam_attn.h)
 // terms = 3: the three-term split (GAM_GEMM_F16X3); terms = 1: hi planes only (GAM_GEMM_F16, opt-in)
-static inline hipError_t gam_launch_attn_mode(const GamAttnArgs& a, int dk, bool split, hipStream_t s, int terms = 3) {
+static inline hipError_t gam_launch_attn_mode(const GamAttnArgs& a, int dk, bool split, hipStream_t s, int terms = 3, int ncu = 256) {
   if (!split) return gam_launch_attn(a, dk, s);
   if (dk != GAM_ATT_DK) return hipErrorInvalidValue;
-  dim3 grid(gam_cdiv(a.Ta, 64 * GAM_ATT_NJ), a.H, a.B);
-  if (terms == 1) {
-    if (a.pbuf != nullptr) hipLaunchKernelGGL((gam_attn_f16x3_kernel<true, 1>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gam_attn_f16x3_kernel<false, 1>), grid, dim3(256), 0, s, a);
+  static const int nj_env = []() { const char* e = getenv("GAM_ATT_NJ_SMALL"); return e ? atoi(e) : -1; }();   // A/B switch (0: never NJ = 1)
+  const long wgs128 = (long)gam_cdiv(a.Ta, 64 * GAM_ATT_NJ) * a.H * a.B;
+  // (measured, same box: one clip 3.10 -> 3.05 ms, 2 x 20 s 4.69 -> 4.64; at 4 x 20 s -- 256 workgroups of 128 queries -- nothing: threshold = one per CU)
+  const bool small = GAM_ATT_NJ == 2 && (nj_env < 0 ? wgs128 < (long)ncu : (nj_env > 0 && wgs128 < (long)nj_env * ncu));
+  const bool rel = a.pbuf != nullptr;
+#define GAM_ATT_GO(REL_, T_, NJ_)                                                                      \
+  hipLaunchKernelGGL((gam_attn_f16x3_kernel<REL_, T_, NJ_>), dim3(gam_cdiv(a.Ta, 64 * NJ_), a.H, a.B), dim3(256), 0, s, a)
+  if (small) {
+    if (terms == 1) { if (rel) GAM_ATT_GO(true, 1, 1); else GAM_ATT_GO(false, 1, 1); }
+    else { if (rel) GAM_ATT_GO(true, 3, 1); else GAM_ATT_GO(false, 3, 1); }
   } else {
-    if (a.pbuf != nullptr) hipLaunchKernelGGL((gam_attn_f16x3_kernel<true, 3>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gam_attn_f16x3_kernel<false, 3>), grid, dim3(256), 0, s, a);
+    if (terms == 1) { if (rel) GAM_ATT_GO(true, 1, GAM_ATT_NJ); else GAM_ATT_GO(false, 1, GAM_ATT_NJ); }
+    else { if (rel) GAM_ATT_GO(true, 3, GAM_ATT_NJ); else GAM_ATT_GO(false, 3, GAM_ATT_NJ); }
   }
+#undef GAM_ATT_GO
   return hipGetLastError();
 }
