@@ -148,3 +148,52 @@ def test_longform_default_vad_falls_back_loudly(monkeypatch):
         res = model.transcribe_longform("unused.wav", min_duration=0.5, max_duration=1.2)
     assert any("EnergyVAD" in str(x.message) for x in w)
     assert [(s.start, s.end) for s in res.segments] == [(0.0, 1.0), (1.5, 3.0)]
+
+
+# ------------------------------------------------------------------ the reference's own segmentation tests, mirrored
+def _long_audio_with_regions(duration, seed):
+    """The recipe of the reference's ``generate_long_audio`` (/root/reference/tests/test_longform.py:65-94: tone bursts of U(0.2, 5) s
+    separated by U(0.1, 0.5) s of silence) with the burst list returned beside the samples -- the list plays the role of the VAD's
+    output (the reference's pyannote model is not installable here)."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    sr = 16000
+    audio = np.zeros(int(sr * duration), dtype=np.float32)
+    regions, t = [], 0.0
+    for i, d in enumerate(rng.uniform(0.2, 5.0, size=100)):
+        if t + d > duration:
+            break
+        n = int(sr * d)
+        tt = np.linspace(0, d, n)
+        seg = 0.4 * np.sin(2 * np.pi * (100 + 20 * i) * tt) + 0.3 * np.sin(2 * np.pi * (200 + 30 * i) * tt) + 0.02 * rng.normal(0, 1, n)
+        a = int(t * sr)
+        audio[a:a + n] = seg[: len(audio) - a]
+        regions.append((t, min(duration, t + d)))
+        t += d + rng.uniform(0.1, 0.5)
+    return audio, regions
+
+
+@pytest.mark.parametrize("duration", [0.5, 30.0, 60.0, 120.0])
+def test_segmentation_boundaries_like_the_reference_tests(duration, tmp_path):
+    """/root/reference/tests/test_longform.py:99-151,208-226 (``validate_segmentation_boundaries``, the 30 / 60 / 120 s cases and the
+    0.5 s edge case) on ``segment_audio_file``: every chunk 0.2 s .. 30 s long, start < end, nothing past the end of the audio, one
+    tensor per boundary -- and a half-second file is handled gracefully (a list comes back)."""
+    import wave
+
+    import numpy as np
+    from gigaam_amd.vad_utils import segment_audio_file
+    audio, regions = _long_audio_with_regions(duration, seed=int(duration * 10))
+    path = str(tmp_path / "long.wav")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+        w.writeframes((np.clip(audio, -1, 1) * 32767).astype(np.int16).tobytes())
+    segments, boundaries = segment_audio_file(path, 16000, speech_regions=regions)
+    assert isinstance(segments, list) and len(segments) == len(boundaries)
+    for (s, e), seg in zip(boundaries, segments):
+        assert s < e and 0.2 <= e - s <= 30.0 + 1e-6, (s, e)
+        assert abs(seg.shape[0] - int(e * 16000) + int(s * 16000)) <= 1
+    if boundaries:
+        assert boundaries[-1][1] <= duration + 1e-6
+        assert all(b0[1] <= b1[0] + 1e-9 for b0, b1 in zip(boundaries, boundaries[1:]))      # ordered, non-overlapping
+    if duration >= 30.0:
+        assert len(boundaries) >= 1 and sum(e - s for s, e in boundaries) > 0.5 * duration
