@@ -51,6 +51,8 @@ SIGNATURES = {
     "gam_ctc_greedy": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P, _P]),
     "gam_rnnt_greedy": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P]),
     "gam_emo_probs": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P]),
+    "gam_rnnt_predict": (C.c_int, [_P, _P, _P, _P, C.c_int, _P, _P, _P, _P]),
+    "gam_rnnt_joint": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "gam_set_gemm_mode": (C.c_int, [_P, C.c_int]),
     "gam_get_gemm_mode": (C.c_int, [_P]),
     "gam_range_flag": (C.c_int, [_P, C.POINTER(C.c_int), _P]),

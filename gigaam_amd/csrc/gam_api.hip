@@ -100,6 +100,8 @@ struct gam_handle {
   float *jn_enc_w = nullptr, *jn_enc_b = nullptr, *jn_pred_t = nullptr, *jn_pred_b = nullptr;
   float *jn_out_w = nullptr, *jn_out_b = nullptr, *lstm_whh_t = nullptr, *lstm_tab = nullptr;
   float *lstm_whh_q = nullptr, *jn_pred_q = nullptr;   // [k/4][row][4] re-layouts for the cluster decode kernel
+  float* jn_pred_w = nullptr;   // W_pred as uploaded ([JH, PH] row-major): the GEMM form of gam_rnnt_joint
+  DevBuf jz, jp, jl;            // gam_rnnt_joint workspace: hidden layer, predictor projection, logits
   float *lstm_wih_x = nullptr, *lstm_whh_x = nullptr, *lstm_bias_x = nullptr;   // predictor layers above the first (gam_decode.h)
   int use_rowscale = 1;         // GAM_ROWSCALE=0: no per-row pre-scale of the LayerNorm-produced GEMM operands (A/B switch)
   int use_range = 1;            // GAM_RANGE=0: no range guard on the unscaled operands (A/B switch)
@@ -509,7 +511,7 @@ void gam_destroy(gam_handle* h) {
   hipSetDevice(h->device);
   for (void* p : h->owned) hipFree(p);
   DevBuf* bufs[] = {&h->wavp, &h->spec, &h->img, &h->c2, &h->xin, &h->y1, &h->x, &h->y, &h->yr, &h->hbuf,
-                    &h->qkv, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes, &h->op_sp, &h->splitk_ws, &h->rsbuf, &h->op_rs, &h->rnnt_x};
+                    &h->qkv, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes, &h->op_sp, &h->splitk_ws, &h->rsbuf, &h->op_rs, &h->rnnt_x, &h->jz, &h->jp, &h->jl};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   if (h->lens) hipFree(h->lens);
@@ -872,6 +874,7 @@ int gam_finalize(gam_handle* h) {
     UP(h->lstm_whh_t, whh_t);
     UP(h->jn_pred_t, wp_t);
     UP(h->jn_pred_b, bp->data);
+    UP(h->jn_pred_w, wp->data);
     UP(h->jn_enc_w, we->data);
     UP(h->jn_enc_b, bee->data);
     UP(h->jn_out_w, wo->data);
@@ -1408,6 +1411,57 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
     }
   }
   return launch_single(0);
+}
+
+int gam_rnnt_predict(gam_handle* h, const int32_t* labels, const float* h_in, const float* c_in, int B, float* g_out,
+                     float* h_out, float* c_out, void* stream) {
+  if (!h || !h->finalized) return fail(h, -1, "gam_rnnt_predict before gam_finalize");
+  if (h->cfg.head_type != GAM_HEAD_RNNT || !h->has_head) return fail(h, -1, "model has no RNN-T head");
+  if (B <= 0 || !g_out || !h_out || !c_out || (h_in == nullptr) != (c_in == nullptr)) return fail(h, -1, "bad gam_rnnt_predict arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  const gam_config& c = h->cfg;
+  GamPredictArgs a;
+  a.label = labels; a.h_in = h_in; a.c_in = c_in; a.g_out = g_out; a.h_out = h_out; a.c_out = c_out;
+  a.gate_tab = h->lstm_tab; a.whh_t = h->lstm_whh_t; a.wih_x = h->lstm_wih_x; a.whh_x = h->lstm_whh_x; a.bias_x = h->lstm_bias_x;
+  a.B = B; a.PH = c.pred_hidden; a.V = c.num_classes; a.L = c.pred_rnn_layers;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(h, s, GAM_PF_DECODE, 0.0);
+  hipLaunchKernelGGL(gam_rnnt_predict_kernel, dim3(B), dim3(256), (size_t)6 * c.pred_hidden * sizeof(float), s, a);
+  HIPCHK(h, hipGetLastError());
+  return 0;
+}
+
+int gam_rnnt_joint(gam_handle* h, const float* enc, const float* dec, int B, int T, int U, float* log_probs, void* stream) {
+  if (!h || !h->finalized) return fail(h, -1, "gam_rnnt_joint before gam_finalize");
+  if (h->cfg.head_type != GAM_HEAD_RNNT || !h->has_head) return fail(h, -1, "model has no RNN-T head");
+  if (B <= 0 || T <= 0 || U <= 0 || !enc || !dec || !log_probs) return fail(h, -1, "bad gam_rnnt_joint arguments");
+  HIPCHK(h, hipSetDevice(h->device));
+  const gam_config& c = h->cfg;
+  const int D = c.d_model, PH = c.pred_hidden, JH = c.joint_hidden, V = c.num_classes;
+  const size_t rows = (size_t)B * T * U;
+  if (rows * std::max(JH, V) > ((size_t)1 << 31)) return fail(h, -1, "gam_rnnt_joint: B x T x U = %zu rows is too large for one call", rows);
+  hipStream_t s = (hipStream_t)stream;
+  if (int r = ensure(h, h->encp, (size_t)B * T * JH)) return r;
+  if (int r = ensure(h, h->jp, (size_t)B * U * JH)) return r;
+  if (int r = ensure(h, h->jz, rows * JH)) return r;
+  if (int r = ensure(h, h->jl, rows * V)) return r;
+  // exact-fp32 MFMA GEMMs like the greedy path's projection (gemm() without split planes): enc [B T, D] and dec [B U, PH]
+  GamGemmArgs ge = gemm_args(enc, D, h->jn_enc_w, h->jn_enc_b, h->encp.p, JH, B * T, JH, D);
+  if (int r = gemm(h, s, ge, GAM_ACT_NONE, GAM_PF_DECODE)) return r;
+  GamGemmArgs gp = gemm_args(dec, PH, h->jn_pred_w, h->jn_pred_b, h->jp.p, JH, B * U, JH, PH);
+  if (int r = gemm(h, s, gp, GAM_ACT_NONE, GAM_PF_DECODE)) return r;
+  {
+    ProfScope ps(h, s, GAM_PF_DECODE, (double)rows * JH * 4.0);
+    const int grid = (int)std::min<size_t>((rows * JH + 255) / 256, 8192);
+    hipLaunchKernelGGL(gam_joint_hidden_kernel, dim3(grid), dim3(256), 0, s, h->encp.p, h->jp.p, h->jz.p, B, T, U, JH);
+    HIPCHK(h, hipGetLastError());
+  }
+  GamGemmArgs go = gemm_args(h->jz.p, JH, h->jn_out_w, h->jn_out_b, h->jl.p, V, (int)rows, V, JH);
+  if (int r = gemm(h, s, go, GAM_ACT_NONE, GAM_PF_DECODE)) return r;
+  ProfScope ps(h, s, GAM_PF_DECODE, (double)rows * V * 8.0);
+  hipLaunchKernelGGL(gam_log_softmax_kernel, dim3(gam_cdiv((long)rows, 4)), dim3(256), 0, s, h->jl.p, log_probs, (int)rows, V);
+  HIPCHK(h, hipGetLastError());
+  return 0;
 }
 
 int gam_emo_probs(gam_handle* h, const float* encoded, const int32_t* enc_len, int B, int64_t Tp, float* probs,

@@ -460,3 +460,76 @@ __global__ __launch_bounds__(256) void gam_emo_head_kernel(const float* __restri
     for (int k = lane; k < NC; k += 64) probs[(size_t)b * NC + k] = expf(logit[k] - mx) / se;
   }
 }
+
+// ------------------------------------------------------------------ RNN-T per-step entry points (r04)
+// The reference exposes its predictor and joint as sub-modules (gigaam/decoder.py:41-47 RNNTJoint.joint, :85-102
+// RNNTDecoder.predict); the greedy loop of this path never calls them (gam_rnnt_greedy evaluates both inside one launch per
+// batch), but a caller that takes the head apart -- the reference's ONNX export, a custom beam search -- needs them.  Plain
+// fp32 kernels on the layouts gam_finalize already builds for the decode kernels; latency is not a concern here.
+
+// One LSTM step of the predictor for B samples: one workgroup per sample.
+//   label[b] in [0, V): embedding row; label[b] < 0 or == V: the zero input of predict(None, ...).
+//   h_in / c_in [L, B, PH] (null: zero state); g_out [B, PH] = top layer's h'; h_out / c_out [L, B, PH].
+struct GamPredictArgs {
+  const int* label;
+  const float *h_in, *c_in;
+  float *g_out, *h_out, *c_out;
+  const float *gate_tab, *whh_t, *wih_x, *whh_x, *bias_x;
+  int B, PH, V, L;
+};
+
+__global__ __launch_bounds__(256) void gam_rnnt_predict_kernel(GamPredictArgs a) {
+  extern __shared__ float gam_smem_pred[];   // x [PH] | h [PH] | gates [4 PH]
+  float* xs = gam_smem_pred;
+  float* hs = xs + a.PH;
+  float* gs = hs + a.PH;
+  const int b = blockIdx.x, tid = threadIdx.x, G = 4 * a.PH;
+  int lab = a.label != nullptr ? a.label[b] : -1;
+  if (lab < 0 || lab > a.V) lab = a.V;       // row V of gate_tab = W_ih . 0 + b_ih + b_hh
+  for (int l = 0; l < a.L; ++l) {
+    const size_t so = ((size_t)l * a.B + b) * a.PH;
+    for (int k = tid; k < a.PH; k += 256) hs[k] = a.h_in != nullptr ? a.h_in[so + k] : 0.f;
+    __syncthreads();
+    for (int r = tid; r < G; r += 256) {
+      float acc;
+      const float* wh;
+      if (l == 0) {
+        acc = a.gate_tab[(size_t)lab * G + r];
+        wh = a.whh_t;
+      } else {
+        acc = a.bias_x[(size_t)(l - 1) * G + r];
+        const float* wi = a.wih_x + (size_t)(l - 1) * a.PH * G;
+        for (int k = 0; k < a.PH; ++k) acc = fmaf(wi[(size_t)k * G + r], xs[k], acc);
+        wh = a.whh_x + (size_t)(l - 1) * a.PH * G;
+      }
+      for (int k = 0; k < a.PH; ++k) acc = fmaf(wh[(size_t)k * G + r], hs[k], acc);
+      gs[r] = acc;
+    }
+    __syncthreads();
+    for (int k = tid; k < a.PH; k += 256) {   // gate order i, f, g, o (nn.LSTM)
+      const float ig = gam_sigmoid_exact(gs[k]), fg = gam_sigmoid_exact(gs[a.PH + k]);
+      const float gg = tanhf(gs[2 * a.PH + k]), og = gam_sigmoid_exact(gs[3 * a.PH + k]);
+      const float c0 = a.c_in != nullptr ? a.c_in[so + k] : 0.f;
+      const float c2 = fg * c0 + ig * gg;
+      const float h2 = og * tanhf(c2);
+      a.c_out[so + k] = c2;
+      a.h_out[so + k] = h2;
+      xs[k] = h2;                              // input of the next layer
+      if (l == a.L - 1) a.g_out[(size_t)b * a.PH + k] = h2;
+    }
+    __syncthreads();
+  }
+}
+
+// z[(b, t, u), :] = relu(encp[b, t, :] + predp[b, u, :])  -- the joint's hidden layer before its output projection
+__global__ __launch_bounds__(256) void gam_joint_hidden_kernel(const float* encp, const float* predp, float* z, int B, int T, int U, int JH) {
+  const size_t n = (size_t)B * T * U * JH;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int j = (int)(i % JH);
+    const size_t row = i / JH;
+    const int u = (int)(row % U);
+    const size_t bt = row / U;
+    const size_t bb = bt / T;
+    z[i] = fmaxf(encp[bt * JH + j] + predp[(bb * U + u) * JH + j], 0.f);
+  }
+}

@@ -25,30 +25,53 @@ class CTCHead(_EngineModule):
 
 
 class _HeadPart:
-    """``head.decoder`` / ``head.joint`` of the reference's RNNTHead (gigaam/decoder.py:24-149) as attribute views: the
-    constructor arguments under the reference's attribute names.  Their per-step entry points (``RNNTDecoder.predict``,
-    ``RNNTJoint.joint``) do not exist on this path -- the predictor, the joint and the greedy loop that calls them
-    (gigaam/decoding.py:128-207) are ONE launch per batch (``gam_rnnt_greedy``) -- and the only reference callers that
-    take these sub-modules apart are the ONNX export (model.py:183-192) and training (train_utils/module.py:130-144),
-    both outside this path: calling them says so instead of failing with an AttributeError."""
+    """``head.decoder`` / ``head.joint`` of the reference's RNNTHead (gigaam/decoder.py:24-149): the constructor arguments under
+    the reference's attribute names, plus the per-step entry points the reference exposes -- ``RNNTDecoder.predict`` and
+    ``RNNTJoint.joint`` / ``forward`` -- as calls into the library (``gam_rnnt_predict`` / ``gam_rnnt_joint``, r04).  The greedy
+    decode of this path never goes through them (predictor, joint and the loop of gigaam/decoding.py:128-207 are ONE launch per
+    batch, ``gam_rnnt_greedy``); they are for callers that take the head apart: a custom search, an export, a numerical check."""
 
-    def __init__(self, kind: str, **cfg: int):
+    def __init__(self, kind: str, owner: "RNNTHead", **cfg: int):
         self._kind = kind
+        self._owner = owner
         self.__dict__.update(cfg)
 
-    def _no_step(self, name: str):
-        raise NotImplementedError(
-            f"RNNTHead.{self._kind}.{name}: the MI355X path evaluates the predictor / joint inside gam_rnnt_greedy, one "
-            "launch per batch (RNNTGreedyDecoding.decode); there is no per-step entry point to export or train through")
+    def _wrong_part(self, name: str):
+        raise AttributeError(f"RNNTHead.{self._kind} has no method {name!r} (it belongs to the other sub-module)")
 
-    def predict(self, *a, **k):
-        self._no_step("predict")
+    def predict(self, x, state, batch_size: int = 1):
+        """RNNTDecoder.predict (gigaam/decoder.py:85-102): x i64 [B,U] labels or None, state (h, c) [L,B,H] or None ->
+        (g [B,U,H], (h', c')).  U > 1 is evaluated step by step (the library call is one step)."""
+        if self._kind != "decoder":
+            self._wrong_part("predict")
+        eng = self._owner.engine
+        if x is None:
+            g, state = eng.rnnt_predict(None, state, batch_size)
+            return g.unsqueeze(1), state
+        if x.dim() == 1:
+            x = x.unsqueeze(1)
+        outs = []
+        for u in range(x.shape[1]):
+            g, state = eng.rnnt_predict(x[:, u], state)
+            outs.append(g)
+        import torch
+        return torch.stack(outs, dim=1), state
 
-    def joint(self, *a, **k):
-        self._no_step("joint")
+    def joint(self, encoder_out, decoder_out):
+        """RNNTJoint.joint (gigaam/decoder.py:41-47): [B,T,enc_hidden], [B,U,pred_hidden] -> log-probs [B,T,U,V]."""
+        if self._kind != "joint":
+            self._wrong_part("joint")
+        return self._owner.engine.rnnt_joint(encoder_out, decoder_out)
 
-    def forward(self, *a, **k):
-        self._no_step("forward")
+    def forward(self, *a):
+        """RNNTJoint.forward(enc [B,enc_hidden,T], dec [B,pred_hidden,U]) (decoder.py:74-75) / RNNTDecoder.forward(x, h, c)
+        (decoder.py:122-137: the export signature, state passed as two tensors)."""
+        if self._kind == "joint":
+            enc, dec = a
+            return self.joint(enc.transpose(1, 2), dec.transpose(1, 2))
+        x, h, c = a
+        g, (h2, c2) = self.predict(x, (h, c))
+        return g, h2, c2
 
     __call__ = forward
 
@@ -61,8 +84,8 @@ class RNNTHead(_EngineModule):
         self.decoder_cfg = dict(decoder)
         self.joint_cfg = dict(joint)
         # (plain objects, not nn.Modules: kept out of the module tree)
-        object.__setattr__(self, "decoder", _HeadPart("decoder", blank_id=self.decoder_cfg["num_classes"] - 1, **self.decoder_cfg))
-        object.__setattr__(self, "joint", _HeadPart("joint", **self.joint_cfg))
+        object.__setattr__(self, "decoder", _HeadPart("decoder", self, blank_id=self.decoder_cfg["num_classes"] - 1, **self.decoder_cfg))
+        object.__setattr__(self, "joint", _HeadPart("joint", self, **self.joint_cfg))
 
     def _cfg_trees(self):
         head: Dict[str, Any] = {"_target_": "RNNTHead", "decoder": self.decoder_cfg, "joint": self.joint_cfg}

@@ -303,6 +303,42 @@ class HipEngine:
             return ids, frames, counts, dump, dcount
         return ids, frames, counts
 
+    def rnnt_predict(self, labels: Optional[Tensor], state: Optional[Tuple[Tensor, Tensor]], batch_size: int = 1):
+        """One predictor step (reference RNNTDecoder.predict, gigaam/decoder.py:85-102): labels i [B] or None (zero input),
+        state (h, c) f32 [L,B,pred_hidden] or None -> (g f32 [B,pred_hidden], (h', c'))."""
+        ph, nl = self.cfg.pred_hidden, self.cfg.pred_rnn_layers
+        if labels is not None:
+            labels = self._dev(labels.reshape(-1), torch.int32)
+            b = labels.shape[0]
+        else:
+            b = batch_size if state is None else state[0].shape[1]
+        h_in = c_in = None
+        if state is not None:
+            h_in, c_in = self._dev(state[0], torch.float32), self._dev(state[1], torch.float32)
+            if tuple(h_in.shape) != (nl, b, ph) or tuple(c_in.shape) != (nl, b, ph):
+                raise GigaAMHipError(f"predictor state must be two [{nl},{b},{ph}] tensors, got {tuple(h_in.shape)} / {tuple(c_in.shape)}")
+        g = torch.empty((b, ph), dtype=torch.float32, device=self.device)
+        h_out = torch.empty((nl, b, ph), dtype=torch.float32, device=self.device)
+        c_out = torch.empty_like(h_out)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gam_rnnt_predict(self._h, _ptr(labels), _ptr(h_in), _ptr(c_in), b, _ptr(g), _ptr(h_out), _ptr(c_out), self._stream())
+        self._check(rc, "gam_rnnt_predict")
+        return g, (h_out, c_out)
+
+    def rnnt_joint(self, enc: Tensor, dec: Tensor) -> Tensor:
+        """Reference RNNTJoint.joint (gigaam/decoder.py:41-47): enc f32 [B,T,d_model], dec f32 [B,U,pred_hidden] ->
+        log-probs f32 [B,T,U,num_classes]."""
+        enc, dec = self._dev(enc, torch.float32), self._dev(dec, torch.float32)
+        b, t, d = enc.shape
+        b2, u, ph = dec.shape
+        if b != b2 or d != self.cfg.d_model or ph != self.cfg.pred_hidden:
+            raise GigaAMHipError(f"joint expects [B,T,{self.cfg.d_model}] and [B,U,{self.cfg.pred_hidden}], got {tuple(enc.shape)} / {tuple(dec.shape)}")
+        out = torch.empty((b, t, u, self.cfg.num_classes), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = self.lib.gam_rnnt_joint(self._h, _ptr(enc), _ptr(dec), b, t, u, _ptr(out), self._stream())
+        self._check(rc, "gam_rnnt_joint")
+        return out
+
     def op_gemm(self, a: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = 0) -> Tensor:
         a = self._dev(a, torch.float32)
         w = self._dev(w, torch.float32)

@@ -112,6 +112,17 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
                     int max_symbols, int32_t* ids, int32_t* frames, int32_t* counts,
                     float* logits_dump, int32_t* dump_count, int dump_cap, void* stream);
 
+/* The RNN-T head taken apart (r04): the per-step entry points the reference exposes as sub-modules.  The greedy decode above
+ * never calls them; they exist for callers that drive their own search or export the head.
+ * gam_rnnt_predict replaces RNNTDecoder.predict (gigaam/decoder.py:85-102) for ONE step of B samples: labels i32 [B] (a value
+ * < 0 is the reference's x = None: zero embedding), h_in / c_in f32 [L, B, pred_hidden] (both NULL: zero state) ->
+ * g_out f32 [B, pred_hidden] (the top layer's new hidden state = the predictor output), h_out / c_out f32 [L, B, pred_hidden].
+ * gam_rnnt_joint replaces RNNTJoint.joint (gigaam/decoder.py:41-47): enc f32 [B, T, d_model], dec f32 [B, U, pred_hidden]
+ * -> log_probs f32 [B, T, U, num_classes] = log_softmax(W_out relu(W_enc enc + W_pred dec)).  Exact-fp32 arithmetic. */
+int gam_rnnt_predict(gam_handle* h, const int32_t* labels, const float* h_in, const float* c_in, int B, float* g_out,
+                     float* h_out, float* c_out, void* stream);
+int gam_rnnt_joint(gam_handle* h, const float* enc, const float* dec, int B, int T, int U, float* log_probs, void* stream);
+
 /* GigaAMEmo.get_probs after the encoder (model.py:277-283): mean over time of encoded f32 [B,d_model,T'],
  * Linear, softmax -> probs f32 [B,num_classes].  enc_len i32 [B] restricts the mean to the valid frames of
  * each utterance; NULL = all T' frames (the reference pools its single unpadded file over the whole axis). */

@@ -245,15 +245,18 @@ def test_attribute_style_cfg_plumbing(tmp_path, monkeypatch):
 def test_rnnt_head_exposes_decoder_and_joint_views():
     """SURVEY 8b lists ``head.decoder`` / ``head.joint`` as attributes the reference reads (model.py:183-192,
     train_utils/module.py:130-144): present here as attribute views with the reference's names; their per-step entry
-    points say why they do not exist instead of raising AttributeError."""
+    points (r04: gam_rnnt_predict / gam_rnnt_joint) need the GPU like every compute call -- there is no CPU path."""
     from gigaam_amd.decoder import RNNTHead
     h = RNNTHead({"pred_hidden": 320, "pred_rnn_layers": 1, "num_classes": 34},
                  {"enc_hidden": 768, "pred_hidden": 320, "joint_hidden": 320, "num_classes": 34})
     assert (h.decoder.pred_hidden, h.decoder.pred_rnn_layers, h.decoder.num_classes, h.decoder.blank_id) == (320, 1, 34, 33)
     assert (h.joint.enc_hidden, h.joint.joint_hidden, h.joint.num_classes) == (768, 320, 34)
-    for call in (lambda: h.decoder.predict(None, None), lambda: h.joint.joint(None, None)):
-        with pytest.raises(NotImplementedError, match="gam_rnnt_greedy"):
+    from gigaam_amd._lib import GigaAMHipError
+    for call in (lambda: h.decoder.predict(None, None), lambda: h.joint.joint(torch.zeros(1, 2, 768), torch.zeros(1, 1, 320))):
+        with pytest.raises(GigaAMHipError, match="no CPU path|ROCm GPU"):
             call()
+    with pytest.raises(AttributeError):
+        h.joint.predict(None, None)
     assert "decoder" not in dict(h.named_children())       # views, not sub-modules: nothing to move or serialise
 
 

@@ -95,3 +95,67 @@ def test_half_precision_state_dict(case, dtype):
         report("half_precision_state_dict_margin", case=case, dtype=str(dtype), margin=margin)
         if margin > 2e-3:
             assert ragged_from_device(*dec(enc, elen)) == want
+
+
+@pytest.mark.parametrize("case", ["v2_rnnt_l2", "v2_rnnt_l2_lstm2", "v3_e2e_rnnt_l2"])
+def test_rnnt_per_step_entry_points(case):
+    """The RNN-T head taken apart (r04: gam_rnnt_predict / gam_rnnt_joint behind ``model.head.decoder.predict`` and
+    ``model.head.joint.joint``, the reference's gigaam/decoder.py:41-47,85-102) against the oracle's per-sample restatement:
+    predictor output and state over a few steps (zero input first, then labels; 1 and 2 LSTM layers), joint log-probs over a
+    [B, T, U] grid -- and a greedy decode DRIVEN THROUGH these entry points reproduces the reference's ids and frames."""
+    import gigaam_amd
+    ck, wav, wlen, gold = load_case(case)
+    sd, cfg = ck["state_dict"], ck["cfg"]
+    nl = cfg["head"]["decoder"]["pred_rnn_layers"]
+    model = gigaam_amd.model_from_checkpoint(ck, "cuda:0", fp16_encoder=False)
+    dec, jnt = model.head.decoder, model.head.joint
+    # --- predictor: x = None with no state, then two label steps for B = 3 samples
+    labels = [torch.tensor([[1], [5], [0]]), torch.tensor([[7], [7], [2]])]
+    g, st = dec.predict(None, None, batch_size=3)
+    want = [O.rnnt_predict(sd, None, None, nl) for _ in range(3)]
+    worst = 0.0
+
+    def cmp(g_, st_, want_):
+        w = 0.0
+        for b, (gw, (hw, cw)) in enumerate(want_):
+            w = max(w, float((g_[b, -1].cpu() - gw).abs().max()), float((st_[0][:, b].cpu() - hw).abs().max()),
+                    float((st_[1][:, b].cpu() - cw).abs().max()))
+        return w
+    with torch.no_grad():
+        worst = max(worst, cmp(g, st, want))
+        for lab in labels:
+            g, st2 = dec.predict(lab.cuda(), st)
+            want = [O.rnnt_predict(sd, int(lab[b, 0]), (want[b][1][0], want[b][1][1]), nl) for b in range(3)]
+            worst = max(worst, cmp(g, st2, want))
+            st = st2
+    assert g.shape == (3, 1, cfg["head"]["decoder"]["pred_hidden"])
+    # --- joint over a grid
+    enc_ref = torch.from_numpy(gold["encoded"])[:2, :, :5].transpose(1, 2).contiguous()      # [2, 5, D]
+    gs = torch.stack([want[0][0], want[1][0], want[2][0]])[:2].unsqueeze(1).repeat(1, 3, 1) * torch.tensor([1.0, 0.5, -1.0])[None, :, None]
+    lp = jnt.joint(enc_ref.cuda(), gs.cuda()).cpu()
+    assert lp.shape == (2, 5, 3, cfg["head"]["joint"]["num_classes"])
+    jw = 0.0
+    with torch.no_grad():
+        for b in range(2):
+            for t in range(5):
+                for u in range(3):
+                    jw = max(jw, float((lp[b, t, u] - O.rnnt_joint(sd, enc_ref[b, t], gs[b, u])).abs().max()))
+    report("rnnt_per_step", case=case, predictor_err=worst, joint_err=jw, tol=1e-4)
+    assert worst < 1e-4 and jw < 1e-3, (worst, jw)
+    # --- the reference's greedy loop (decoding.py:162-205), one sample, driven through the entry points
+    enc1 = torch.from_numpy(gold["encoded"])[:1]
+    n = int(gold["enc_len"][0])
+    blank = cfg["head"]["decoder"]["num_classes"] - 1
+    ms = cfg["decoding"]["max_symbols_per_step"]
+    ids, frames, label, state = [], [], None, None
+    x = enc1.transpose(1, 2).cuda()
+    for t in range(n):
+        for _ in range(ms):
+            g1, new_state = dec.predict(None if label is None else torch.tensor([[label]]).cuda(), state, batch_size=1)
+            k = int(jnt.joint(x[:, t:t + 1], g1)[0, 0, 0].argmax())
+            if k == blank:
+                break
+            ids.append(k); frames.append(t)
+            label, state = k, new_state
+    c0 = int(gold["counts"][0])
+    assert ids == gold["ids"][:c0].tolist() and frames == gold["frames"][:c0].tolist()
