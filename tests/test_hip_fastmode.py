@@ -113,3 +113,26 @@ def test_encoder_in_speed_mode(case):
     assert 1e-4 < err < TOL_ENC_F16, err        # (> 1e-4: this IS the narrower arithmetic, not the default mode by mistake)
     assert all(len(i) == len(f) for i, f in got)
     assert not eng.range_flag()
+
+
+@pytest.mark.parametrize("case", ["v2_ctc_l2", "v1_ctc_l2", "v3_ctc_l2"])
+def test_speed_mode_on_a_large_grid(case):
+    """The kernels a LARGE grid takes in the speed mode -- 128-query attention workgroups (rotary and relative-position), the
+    8-wave GEMM tiles, no split-K -- on 6 x 30 s through the two-layer models: close to the default mode's output (which the
+    long-utterance parity tests pin to the oracle), same lengths, no range flag."""
+    from gigaam_amd import synth
+    ck, _, _, _ = load_case(case)
+    eng = _engine(ck)
+    wav, wlen = synth.synth_audio(6, 30.0, seed=11, lengths=[480000, 470000, 300000, 480000, 123456, 480000])
+    feat, flen = eng.frontend(wav, wlen)
+    enc3, elen3 = eng.encode(feat, flen)
+    eng.set_gemm_mode("f16")
+    enc1, elen1 = eng.encode(*eng.frontend(wav, wlen))
+    assert elen1.cpu().tolist() == elen3.cpu().tolist()
+    vm = valid_mask(enc3.shape[2], elen3.cpu())[:, None, :].to(enc3.device)
+    err = float(((enc1 - enc3) * vm).abs().max())
+    report("speed_mode_large_grid", case=case, err_vs_default=err, tol=TOL_ENC_F16)
+    assert 1e-5 < err < TOL_ENC_F16, err
+    assert not eng.range_flag()
+    out = ragged_from_device(*eng.ctc_greedy(enc1, elen1))
+    assert all(len(i) == len(f) and (not f or f[-1] < n) for (i, f), n in zip(out, elen1.cpu().tolist()))
