@@ -336,16 +336,44 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
   // (r04, tried and dropped: requesting the bias pieces and the row scales of the 4-wave tiles in front of the first k-tile, so
   //  that the epilogue of a small-grid launch does not start with an L2 round trip -- 32 + MT more live registers, same-box A/B
   //  6.22-6.24 vs 6.24-6.25 ms at 4 x 20 s, 2.85 vs 2.89 ms for one clip: nothing; profiles/r04_ab_experiments.txt)
-  const int lrow = lane & 31, lq = (lane >> 5) * 4;
+  // r04: EIGHT consecutive columns per lane.  Lanes l and l + 32 hold the two halves of every 8-column group of their (common) row;
+  // one v_permlane32_swap per register trades the second half of the even group against the first half of the odd one, after
+  // which lane l < 32 owns columns 16 p .. 16 p + 7 and lane l + 32 columns 16 p + 8 .. 16 p + 15 of each 32-column block: bias /
+  // residual / C move as pairs of adjacent 16-byte pieces (64 contiguous bytes per row per instruction instead of 32), and an
+  // sp32 / fp16 result as ONE 16-byte store per plane instead of two 8-byte ones (the store path, not the arithmetic, is what an
+  // epilogue costs: profiles/r03_gemm_timeline.txt).  (semantics probed on the device, tools/permlane_probe.hip: after the instruction
+  // vdst = [vdst(0..31) | vsrc(0..31)], vsrc = [vdst(32..63) | vsrc(32..63)].)  Same values, same roundings: bit-identical results.
+  // Inline asm, not __builtin_amdgcn_permlane32_swap: hipcc 7.2 miscompiles a SEQUENCE of the builtin on vector elements (every
+  // element comes back as element 0 -- reproduced in isolation by the probe).  The asm reads MFMA results and the hazard
+  // recognizer does not look inside asm: two s_nop 15 cover the XDL-write -> VALU-read wait states of the last MFMAs.
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int pq = 0; pq < 2; ++pq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[i][j][8 * pq + r], y = acc[i][j][8 * pq + 4 + r];
+          asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+          acc[i][j][8 * pq + r] = x;
+          acc[i][j][8 * pq + 4 + r] = y;
+        }
+  const int lrow = lane & 31, lq8 = (lane >> 5) * 8;
   const float accscale = g.wscale_inv;
-  f32x4 bv[2][4];
+  // piece (j, pq, hf): columns nw + 32 j + 16 pq + lq8 + 4 hf .. + 3  =  accumulator registers 8 pq + 4 hf .. + 3
+  f32x4 bv[2][2][2];
 #pragma unroll
   for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int col = nw + 32 * j + 8 * q + lq;
-      bv[j][q] = (g.bias != nullptr && col < g.N) ? *reinterpret_cast<const f32x4*>(g.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};   // N % 4 == 0
-    }
+    for (int pq = 0; pq < 2; ++pq)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int col = nw + 32 * j + 16 * pq + lq8 + 4 * hf;
+        bv[j][pq][hf] = (g.bias != nullptr && col < g.N) ? *reinterpret_cast<const f32x4*>(g.bias + col) : (f32x4){0.f, 0.f, 0.f, 0.f};   // N % 4 == 0
+      }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int row = mw + 32 * i + lrow;
@@ -368,49 +396,70 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int ecol = nw + 32 * j + 8 * q + lq;
-          if (ecol < g.N)
-            *reinterpret_cast<f32x4*>(P + ecol) = (f32x4){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]} * rsc;
-        }
+        for (int pq = 0; pq < 2; ++pq)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const int ecol = nw + 32 * j + 16 * pq + lq8 + 4 * hf, r0 = 8 * pq + 4 * hf;
+            if (ecol < g.N)
+              *reinterpret_cast<f32x4*>(P + ecol) = (f32x4){acc[i][j][r0], acc[i][j][r0 + 1], acc[i][j][r0 + 2], acc[i][j][r0 + 3]} * rsc;
+          }
       continue;
     }
-    f32x4 rv[2][4];
+    f32x4 rv[2][2][2];
     if (g.R != nullptr) {   // all eight residual pieces of the row in flight before the first use
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int col = nw + 32 * j + 8 * q + lq;
-          rv[j][q] = col < g.N ? *reinterpret_cast<const f32x4*>(g.R + orow * g.ldr + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+        for (int pq = 0; pq < 2; ++pq)
+#pragma unroll
+          for (int hf = 0; hf < 2; ++hf) {
+            const int col = nw + 32 * j + 16 * pq + lq8 + 4 * hf;
+            rv[j][pq][hf] = col < g.N ? *reinterpret_cast<const f32x4*>(g.R + orow * g.ldr + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int ecol = nw + 32 * j + 8 * q + lq;
+      for (int pq = 0; pq < 2; ++pq) {
+        const int ecol = nw + 32 * j + 16 * pq + lq8;      // first of this lane's eight columns
         if (ecol >= g.N) continue;
-        f32x4 v = (f32x4){acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        v = v * rsc + bv[j][q];
-        if (ACT == GAM_ACT_SILU) { v.x = gam_silu(v.x); v.y = gam_silu(v.y); v.z = gam_silu(v.z); v.w = gam_silu(v.w); }
-        if (ACT == GAM_ACT_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        if (masked) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-        v = v * g.alpha;
-        if (g.R != nullptr) v += rv[j][q];
-        if (g.c_guard) gam_range_note(g.range_flag, v.x, v.y, v.z, v.w);
-        if ((GAM_SP_DBG(g) & 32) && v.x != 123.456f) continue;   // (experiment: the whole epilogue except its global stores)
-        if (g.c_split == 2) {   // plain fp16 rows (the one-term mode's operand format)
+        const bool both = ecol + 4 < g.N;                    // (N % 8 == 4: the last group has its first half only)
+        f32x4 v[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const int r0 = 8 * pq + 4 * hf;
+          f32x4 t = (f32x4){acc[i][j][r0], acc[i][j][r0 + 1], acc[i][j][r0 + 2], acc[i][j][r0 + 3]};
+          t = t * rsc + bv[j][pq][hf];
+          if (ACT == GAM_ACT_SILU) { t.x = gam_silu(t.x); t.y = gam_silu(t.y); t.z = gam_silu(t.z); t.w = gam_silu(t.w); }
+          if (ACT == GAM_ACT_RELU) { t.x = fmaxf(t.x, 0.f); t.y = fmaxf(t.y, 0.f); t.z = fmaxf(t.z, 0.f); t.w = fmaxf(t.w, 0.f); }
+          if (masked) t = (f32x4){0.f, 0.f, 0.f, 0.f};
+          t = t * g.alpha;
+          if (g.R != nullptr) t += rv[j][pq][hf];
+          if (!both && hf == 1) t = (f32x4){0.f, 0.f, 0.f, 0.f};
+          v[hf] = t;
+        }
+        if (g.c_guard) { gam_range_note(g.range_flag, v[0].x, v[0].y, v[0].z, v[0].w); gam_range_note(g.range_flag, v[1].x, v[1].y, v[1].z, v[1].w); }
+        if ((GAM_SP_DBG(g) & 32) && v[0].x != 123.456f) continue;   // (experiment: the whole epilogue except its global stores)
+        if (g.c_split == 2) {   // plain fp16 rows (the one-term mode's operand format): 8 halfs = one 16-byte store
           _Float16* cp = reinterpret_cast<_Float16*>(g.C) + orow * g.ldc + ecol;
-          *reinterpret_cast<gam_half4*>(cp) = __builtin_convertvector(v, gam_half4);
+          const gam_half4 h0 = __builtin_convertvector(v[0], gam_half4), h1 = __builtin_convertvector(v[1], gam_half4);
+          if (both) *reinterpret_cast<gam_half8*>(cp) = (gam_half8){h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+          else *reinterpret_cast<gam_half4*>(cp) = h0;
         } else if (g.c_split) {
           _Float16* cp = reinterpret_cast<_Float16*>(g.C) + orow * (2 * g.ldc) + (ecol >> 5) * 64 + (ecol & 31);
-          gam_half4 hi, lo;
-          gam_split4(v, hi, lo);
-          *reinterpret_cast<gam_half4*>(cp) = hi;
-          *reinterpret_cast<gam_half4*>(cp + 32) = lo;
+          gam_half4 hi0, lo0, hi1, lo1;
+          gam_split4(v[0], hi0, lo0);
+          gam_split4(v[1], hi1, lo1);
+          if (both) {
+            *reinterpret_cast<gam_half8*>(cp) = (gam_half8){hi0[0], hi0[1], hi0[2], hi0[3], hi1[0], hi1[1], hi1[2], hi1[3]};
+            *reinterpret_cast<gam_half8*>(cp + 32) = (gam_half8){lo0[0], lo0[1], lo0[2], lo0[3], lo1[0], lo1[1], lo1[2], lo1[3]};
+          } else {
+            *reinterpret_cast<gam_half4*>(cp) = hi0;
+            *reinterpret_cast<gam_half4*>(cp + 32) = lo0;
+          }
         } else {
-          *reinterpret_cast<f32x4*>(g.C + orow * g.ldc + ecol) = v;
+          *reinterpret_cast<f32x4*>(g.C + orow * g.ldc + ecol) = v[0];
+          if (both) *reinterpret_cast<f32x4*>(g.C + orow * g.ldc + ecol + 4) = v[1];
         }
       }
   }
