@@ -28,7 +28,8 @@ Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
                       events on the launch stream inside the timed region; achieved = algorithmic FLOP / event time
   roofline_f32_exact  the same steps re-timed with the dense contractions on exact-fp32 MFMA (the reference's own
                       arithmetic), so that figure is on the driver's clock too
-  cpu_baseline        the CPU oracle (a port of the reference's fp32 CPU path) on this box's host cores (N=1 only)
+  cpu_baseline        the REFERENCE's own modules (oracle/_ref, built by oracle/build_ref.py from /root/reference) on this
+                      box's host cores (N=1 only), ids compared with the GPU's for every utterance of the sample
 """
 from __future__ import annotations
 
@@ -233,56 +234,122 @@ class PowerSampler:
 
 
 # ----------------------------------------------------------------------------- cpu baseline
-def cpu_baseline(ckpt, wav, wlen, n_utts: int, gpu_decoded, sweep: bool):
-    """The CPU oracle (fp32 port of the reference's CPU path) on this box's host cores.  With ``sweep`` the thread
-    count is chosen by timing a small sample at 8 / 16 / 32 / 64 threads (many small fp32 ops: beyond a few dozen
-    threads the oracle gets slower on a many-core host), then all ``n_utts`` utterances run at the best setting.
-    Also reports how many of those utterances decode to exactly the GPU's ids/frames."""
+def _ref_margin_of(model, is_rnnt, enc, elen, i):
+    """Smallest top-1 / top-2 log-prob margin the REFERENCE saw while decoding utterance i (untimed; only called for an
+    utterance whose GPU ids differ, to tell a near-tie of a random-weight head from a real disagreement)."""
+    n = int(elen[i])
+    e1 = enc[i:i + 1, :, :n].contiguous()
+    if not is_rnnt:
+        lp = model.head(e1)
+        t2 = lp.topk(2, dim=-1).values
+        return float((t2[..., 0] - t2[..., 1]).min())
+    rec, orig = [], model.head.joint.joint
+
+    def spy(f, g):
+        out = orig(f, g)
+        t2 = out.reshape(-1, out.shape[-1]).topk(2, dim=-1).values
+        rec.append(float((t2[:, 0] - t2[:, 1]).min()))
+        return out
+    model.head.joint.joint = spy
+    try:
+        model.decoding.decode(model.head, e1, elen[i:i + 1])
+    finally:
+        del model.head.joint.joint
+    return min(rec) if rec else None
+
+
+def cpu_baseline(ckpt, batches, gpu_decoded, sweep: bool, equal_lengths: bool, port_too: bool):
+    """The reference's OWN modules (oracle/_ref: CPython bytecode of /root/reference/gigaam/*.py made by oracle/build_ref.py,
+    imported through oracle/ref_shim.py) on this box's host cores, fp32: ``GigaAM.forward`` (FeatureExtractor ->
+    ConformerEncoder, gigaam/model.py:27-37) + ``decoding.decode(head, ...)`` (model.py:96-124) = the body of
+    ``transcribe()`` (model.py:126-140) behind ``load_audio``, batched.  ``batches`` = [(wav [b,L], wlen [b])] host tensors,
+    each exactly as the GPU decoded it (a ragged batch must be seen whole: the reference's features of an utterance's last
+    frames depend on its row's padding); equal-length batches are fed two utterances per call (larger CPU batches run slower
+    per utterance).  With ``sweep`` the thread count is the best of 8 / 16 / 32 / 64 on a two-utterance sample.  Reports how
+    many utterances decode to exactly the GPU's ids AND frames; for a mismatch, the reference's own smallest top-1/top-2
+    margin on that utterance.  ``port_too``: oracle/gigaam_oracle.py (the restatement the tests use) timed beside it.
+    Falls back to the port alone (kind = "port") only when oracle/_ref is missing, and says so."""
     from oracle import gigaam_oracle as O
+    from oracle import ref_shim
     ncpu = os.cpu_count() or 1
-    w, l = wav[:n_utts].cpu(), wlen[:n_utts].cpu()
+    is_rnnt = "RNNT" in ckpt["cfg"]["decoding"]["_target_"]
+    use_ref = ref_shim.reference_available()
+    model = ref_shim.reference_model(ckpt) if use_ref else None
+
+    def run_ref(w, l):
+        with torch.inference_mode():
+            enc, elen = model.forward(w, l)
+            dec = model.decoding.decode(model.head, enc, elen)
+        return [(list(i), list(f)) for _, i, f in dec], enc, elen
+
+    def run_port(w, l):
+        with torch.no_grad():
+            dec, enc, elen = O.transcribe_ids(ckpt, w, l)
+        return [(list(i), list(f)) for i, f in dec], enc, elen
+
+    run = run_ref if use_ref else run_port
+    calls = []                      # (wav, wlen) per CPU call
+    for w, l in batches:
+        w, l = w.cpu(), l.cpu()
+        if equal_lengths:
+            calls += [(w[i:i + 2].contiguous(), l[i:i + 2].contiguous()) for i in range(0, w.shape[0], 2)]
+        else:
+            calls.append((w, l))
+    n_utts = sum(int(l.shape[0]) for _, l in calls)
+    audio_s = float(sum(int(l.sum()) for _, l in calls)) / 16000.0
     sweep_out = {}
     best = min(32, ncpu)
-    with torch.no_grad():
-        torch.set_num_threads(best)
-        O.transcribe_ids(ckpt, w[:1, :16000].contiguous(), torch.tensor([16000]))  # warm-up
-        if sweep:
-            for th in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu)}):
-                torch.set_num_threads(th)
-                ws, ls = w[:min(2, n_utts)], l[:min(2, n_utts)]
-                t0 = time.perf_counter()
-                O.transcribe_ids(ckpt, ws, ls)
-                sweep_out[th] = round(float(ls.sum()) / 16000.0 / (time.perf_counter() - t0), 2)
-            best = max(sweep_out, key=sweep_out.get)
-        torch.set_num_threads(best)
-        t0 = time.perf_counter()
-        dec = []
-        for i in range(0, n_utts, 2):      # two utterances per oracle call: larger batches run slower per utterance on the CPU
-            dec += O.transcribe_ids(ckpt, w[i:i + 2], l[i:i + 2])[0]
-        dt = time.perf_counter() - t0
-    audio_s = float(l.sum()) / 16000.0
-    same = [list(a) == list(b) and list(c) == list(d) for (a, c), (b, d) in zip(dec, gpu_decoded[:n_utts])]
+    torch.set_num_threads(best)
+    run(calls[0][0][:1, :16000].contiguous(), torch.tensor([16000]))  # warm-up
+    if sweep:
+        ws, ls = calls[0][0][:2], calls[0][1][:2]
+        for th in sorted({min(8, ncpu), min(16, ncpu), min(32, ncpu), min(64, ncpu)}):
+            torch.set_num_threads(th)
+            t0 = time.perf_counter()
+            run(ws, ls)
+            sweep_out[th] = round(float(ls.sum()) / 16000.0 / (time.perf_counter() - t0), 2)
+        best = max(sweep_out, key=sweep_out.get)
+    torch.set_num_threads(best)
+    t0 = time.perf_counter()
+    outs = [run(w, l) for w, l in calls]
+    dt = time.perf_counter() - t0
+    dec = [d for o in outs for d in o[0]]
+    same = [a == (list(b[0]), list(b[1])) for a, b in zip(dec, gpu_decoded[:n_utts])]
     out = {
-        "value": round(audio_s / dt, 3), "unit": "audio-sec/wall-sec", "cores": best, "host_cpus": ncpu, "kind": "port",
-        "sample": f"{n_utts} utterances of the timed batch ({audio_s:.0f} s audio) in calls of 2, oracle/gigaam_oracle.py fp32, {dt:.1f} s wall",
+        "value": round(audio_s / dt, 3), "unit": "audio-sec/wall-sec", "cores": best, "host_cpus": ncpu,
+        "kind": "reference" if use_ref else "port",
+        "sample": (f"{n_utts} utterances ({audio_s:.0f} s audio) of the timed workload in {len(calls)} call(s) "
+                   f"({'two equal-length utterances per call' if equal_lengths else 'each ragged batch whole, as the GPU decoded it'}), "
+                   f"{dt:.1f} s wall, fp32, torch {torch.__version__} CPU"),
         "gpu_ids_identical": f"{sum(same)}/{len(same)}",
-        "reference_cpu": "unavailable on the GPU box (/root/reference is not shipped); the oracle is pinned to the reference's "
-                         "own modules by tests/golden/*.npz",
     }
-    rp = os.path.join(ROOT, "profiles", "r03_cpu_ref_vs_port.json")
-    if os.path.exists(rp):   # the reference's own modules timed beside this port in the build container (tools/cpu_ref_vs_port.py)
-        rj = json.load(open(rp))
-        out["reference_rtfx_build_container"] = rj["reference_rtfx"]
-        out["port_rtfx_build_container"] = rj["port_rtfx"]
-        out["port_over_reference"] = rj["port_over_reference"]
-        out["reference_build_container_threads"] = rj["threads"]
-        out["note"] = (f"reference modules vs this port on the same {rj['utterances']} utterances, {rj['threads']} threads, build container: "
-                       f"reference {rj['reference_rtfx']}x, port {rj['port_rtfx']}x real time (port/reference = {rj['port_over_reference']}); "
-                       "profiles/r03_cpu_ref_vs_port.json")
+    if use_ref:
+        out["what"] = ("the reference's own GigaAMASR.forward + decoding.decode (= transcribe() behind load_audio; "
+                       f"oracle/_ref {ref_shim.import_reference().kind} of /root/reference/gigaam, sha256 in oracle/ref_manifest.json); "
+                       "torchaudio.transforms.MelSpectrogram is a stand-in on torch.stft (not installed here: row a1)")
+    else:
+        out["what"] = "oracle/gigaam_oracle.py (fp32 port of the reference's CPU path): oracle/_ref is MISSING on this box -- run oracle/build_ref.py"
     if sweep_out:
         out["thread_sweep_rtfx"] = {str(k): v for k, v in sweep_out.items()}
     if sum(same) != len(same):
-        out["mismatching_utterances"] = [i for i, s in enumerate(same) if not s]
+        bad = [i for i, s in enumerate(same) if not s]
+        out["mismatching_utterances"] = bad
+        if use_ref:     # near-tie or real?  (row i of the concatenated calls -> its call and row)
+            rows, k = {}, 0
+            for ci, (_, l) in enumerate(calls):
+                for r in range(int(l.shape[0])):
+                    rows[k] = (ci, r)
+                    k += 1
+            with torch.inference_mode():
+                out["mismatch_reference_min_margin"] = {str(i): _ref_margin_of(model, is_rnnt, outs[rows[i][0]][1], outs[rows[i][0]][2], rows[i][1])
+                                                        for i in bad[:8]}
+    if use_ref and port_too:
+        t0 = time.perf_counter()
+        pdec = [d for w, l in calls for d in run_port(w, l)[0]]
+        dtp = time.perf_counter() - t0
+        out["port"] = {"value": round(audio_s / dtp, 3), "cores": best, "wall_s": round(dtp, 1),
+                       "ids_identical_to_reference": f"{sum(a == b for a, b in zip(pdec, dec))}/{len(dec)}",
+                       "what": "oracle/gigaam_oracle.py on the same calls (the restatement the parity tests use)"}
     return out
 
 
@@ -386,11 +453,15 @@ def main():
     ap.add_argument("--model", default=None, help="override the configuration's model")
     ap.add_argument("--batch", type=int, default=32, help="configs 2/3: utterances per GPU (weak) or in total (strong)")
     ap.add_argument("--seconds", type=float, default=20.0)
+    ap.add_argument("--ragged", action="store_true", help="configs 2/3: utterance lengths linspace(seconds/2, seconds, batch) instead of equal "
+                    "(SURVEY 8d's second run); the CPU reference leg then decodes the batch whole")
     ap.add_argument("--utts-per-gpu", type=int, default=128, help="config 4, weak scaling")
     ap.add_argument("--longform-seconds", type=int, default=3600, help="config 5")
     ap.add_argument("--fr-batch", type=int, default=16, help="config 5: chunks per batch (the reference's fr_batch_size default)")
     ap.add_argument("--layers", type=int, default=-1, help="debug only: fewer layers INVALIDATES the number")
-    ap.add_argument("--cpu-utts", type=int, default=-1, help="utterances in the CPU-oracle leg (0 = skip; default: 32 for config 2, 4 otherwise)")
+    ap.add_argument("--cpu-utts", type=int, default=-1, help="utterances in the CPU reference leg (0 = skip; default: 32 -- all of configs 2 / 3, "
+                    "the first batch of config 4, the first two batches of config 5)")
+    ap.add_argument("--no-port-leg", action="store_true", help="config 2: do not time oracle/gigaam_oracle.py beside the reference")
     ap.add_argument("--rnnt-blank-bias", type=float, default=None,
                     help="RNN-T models: blank bias of the synthetic joint (default: the blank-dominant value of tests/golden/fullsize_meta.json)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
@@ -467,7 +538,7 @@ def main():
         return eng.rnnt_greedy(enc, elen, max_sym) if is_rnnt else eng.ctc_greedy(enc, elen)
 
     # ---- the step of each configuration; `audio_s` = audio seconds ALL ranks process per step
-    cpu_sample = None       # (wav, wlen) on the host + global indices, for the CPU-oracle leg
+    cpu_sample = None       # ([(wav, wlen)] host batches exactly as the GPU decodes them, their global indices) for the CPU leg
     if cfgno in (1, 2, 3):
         if cfgno == 1:
             n_global, seconds = 1, 5.0
@@ -477,12 +548,19 @@ def main():
             seconds = args.seconds
             g0, g1 = shard_range(n_global, rank, n_ranks)
         wav_h, wlen_h = workloads.config2_batch(max(1, g1 - g0), seconds, first=g0) if cfgno != 1 else workloads.config1_clip()
+        ragged_global = None
+        if args.ragged and cfgno != 1:
+            # SURVEY 8d's second run of config 2 / 3: lengths linspace(10 s, 20 s, batch) -- masks, ragged frame counts, padded tails
+            pat = workloads.config2_ragged_lengths(args.batch, 0.5 * seconds, seconds)
+            ragged_global = pat * n_ranks if scaling == "weak" else pat
+            mine_l = ragged_global[g0:g1] or [int(seconds * 16000)]
+            wav_h, wlen_h = synth.synth_audio(len(mine_l), seconds, seed=1000, index0=g0, lengths=mine_l)
         wav, wlen = wav_h.to(dev), wlen_h.to(dev)          # resident in HBM before the timed region
         rows = max(shard_range(n_global, r, n_ranks)[1] - shard_range(n_global, r, n_ranks)[0] for r in range(n_ranks))
-        audio_s = seconds * n_global
+        audio_s = seconds * n_global if ragged_global is None else sum(ragged_global) / 16000.0
         idx_dev = torch.full((rows,), -1, dtype=torch.int32, device=dev)
         idx_dev[: g1 - g0] = torch.arange(g0, g1, dtype=torch.int32, device=dev)
-        cpu_sample = (wav_h, wlen_h, list(range(g0, g1)))
+        cpu_sample = ([(wav_h, wlen_h)], list(range(g0, g1)))
 
         def step():
             if g1 > g0:
@@ -501,7 +579,8 @@ def main():
                     raise RuntimeError("split-fp16 range flag set on some rank during a bench step")
                 return dec
             return ragged_host(ids, frames, counts)        # the decoded ids (+ the range flag at N = 1) end every step on the host
-        workload = (f"{model_name} (16-layer Conformer, random-init weights), {n_global} x {seconds:g} s 16 kHz utterances "
+        workload = (f"{model_name} (16-layer Conformer, random-init weights), {n_global} x "
+                    f"{'linspace(%g s, %g s) RAGGED' % (0.5 * seconds, seconds) if ragged_global else '%g s' % seconds} 16 kHz utterances "
                     f"({'%d per GPU' % args.batch if scaling == 'weak' else 'global batch split over the ranks'}), frontend + encoder + "
                     f"{'RNN-T' if is_rnnt else 'CTC'} greedy + ids to host, final gather of ids")
     elif cfgno == 4:
@@ -513,7 +592,7 @@ def main():
         cap = eng.enc_frames(eng.feat_frames(20 * 16000)) * max_sym
         tok = model.decoding.tokenizer
         if rank == 0 and host_batches:
-            cpu_sample = (host_batches[mine[0]][0], host_batches[mine[0]][1], host_batches[mine[0]][2])
+            cpu_sample = ([(host_batches[mine[0]][0], host_batches[mine[0]][1])], list(host_batches[mine[0]][2]))
 
         def step():
             # batch n is launched before batch n-1's ids are copied back (shard.run_sharded, collect=)
@@ -545,16 +624,16 @@ def main():
         feeder = BatchFeeder(my_segs, fr_bs, dev) if my_segs else []       # pinned staging buffers: allocated once
         last5 = {}
         if rank == 0:
-            # CPU-oracle leg: four rows of the batch that holds the file's longest chunk (rank 0's first batch: LPT deals the
-            # longest chunk first, to rank 0), cut from that batch's OWN zero-padded tensor -- the reference's features of an
-            # utterance's last frames depend on what follows it in its row (zero padding inside a batch, reflect padding at the
-            # end of the longest row: torchaudio center=True pads the TENSOR), so the oracle must see each chunk exactly as the
-            # GPU's batch held it, not re-collated with other neighbours
+            # CPU leg: rank 0's first two batches (2 x fr_batch_size chunks; LPT deals the file's longest chunk first, to rank 0),
+            # each collated on its own -- the reference's features of an utterance's last frames depend on what follows it in
+            # its row (zero padding inside a batch, reflect padding at the end of the longest row: torchaudio center=True pads
+            # the TENSOR), so the reference must see each chunk exactly as the GPU's batch held it
             from gigaam_amd.feeder import collate
-            rows5 = list(my_batches[0])
-            w5, l5 = collate([segs[i] for i in rows5])
-            sel = sorted(range(len(rows5)), key=lambda r: -int(l5[r]))[:4]
-            cpu_sample = (w5[sel].contiguous(), l5[sel].contiguous(), [rows5[r] for r in sel])
+            b5, g5 = [], []
+            for rows5 in my_batches[:2]:
+                b5.append(collate([segs[i] for i in rows5]))
+                g5 += list(rows5)
+            cpu_sample = (b5, g5)
 
         trace = os.environ.get("GAM_BENCH_TRACE")   # debug: host timestamps per batch (ms since the step began)
 
@@ -811,7 +890,7 @@ def main():
                                    "note": "768->320 projection GEMM + gam_rnnt_cluster_kernel; the utterances of a batch decode "
                                            "concurrently (one workgroup cluster each), a 16-frame window per hand-off round"}
         if cfgno in (2, 3):
-            whole = FLOP_PER_UTT_20S_V2 * (args.seconds / 20.0) * (g1 - g0) / (ms_step * 1e-3) / 1e12
+            whole = FLOP_PER_UTT_20S_V2 * (float(wlen_h.sum()) / 16000.0 / 20.0 if g1 > g0 else 0.0) / (ms_step * 1e-3) / 1e12
             line["whole_path_tflops_per_gpu"] = round(whole, 2)
     if power is not None:
         line["board_power"] = power
@@ -849,19 +928,34 @@ def main():
         if margins is not None:
             leg["ctc_margins"] = margins
         line["roofline_f16_fast"] = leg
-    n_cpu = args.cpu_utts if args.cpu_utts >= 0 else (32 if cfgno == 2 else 4)
+    n_cpu = args.cpu_utts if args.cpu_utts >= 0 else 32
     if n_ranks == 1 and n_cpu > 0 and cpu_sample is not None:
         try:
-            w_h, l_h, gidx = cpu_sample
+            cb, gidx = cpu_sample
+            # at most n_cpu utterances: whole batches, the last one cut by ROWS only (the padded width -- what the reference's
+            # reflect / zero padding sees -- stays the batch's own)
+            keep, left = [], n_cpu
+            for w_h, l_h in cb:
+                if left <= 0:
+                    break
+                k = min(left, int(w_h.shape[0]))
+                keep.append((w_h[:k].contiguous(), l_h[:k].contiguous()))
+                left -= k
+            offs, sel = 0, []
+            for (w_h, _), (wk, _) in zip(cb, keep):
+                sel += gidx[offs: offs + int(wk.shape[0])]
+                offs += int(w_h.shape[0])
             if cfgno in (1, 2, 3):
-                gpu_dec = decoded_mine
+                gpu_dec = [decoded_mine[g - g0] for g in sel]
             elif cfgno == 4:
-                gpu_dec = [(out[g][0], out[g][1]) for g in gidx]
+                gpu_dec = [(out[g][0], out[g][1]) for g in sel]
             else:
-                gpu_dec = [tuple(last5["res"][g]) for g in gidx]
-            line["cpu_baseline"] = cpu_baseline(ckpt, w_h, l_h, min(n_cpu, w_h.shape[0]), gpu_dec, sweep=(cfgno == 2))
+                gpu_dec = [tuple(last5["res"][g]) for g in sel]
+            line["cpu_baseline"] = cpu_baseline(ckpt, keep, gpu_dec, sweep=(cfgno == 2), equal_lengths=cfgno in (1, 2, 3) and not args.ragged,
+                                                port_too=(cfgno == 2 and not args.no_port_leg))
         except Exception as e:  # the bench line must still print
-            line["cpu_baseline"] = {"error": repr(e)}
+            import traceback
+            line["cpu_baseline"] = {"error": repr(e), "traceback": traceback.format_exc()[-600:]}
     emit(line, n_ranks)
 
 

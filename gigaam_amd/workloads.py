@@ -30,6 +30,18 @@ def config2_batch(batch: int = 32, seconds: float = 20.0, rank: int = 0, first: 
     return synth.synth_audio(batch, seconds, seed=1000, index0=i0)
 
 
+def config2_ragged_lengths(batch: int = 32, lo_s: float = 10.0, hi_s: float = 20.0) -> List[int]:
+    """SURVEY.md §8d, config 2's second run: lengths ``linspace(10 s, 20 s, batch)`` (in samples), longest LAST -- the masks,
+    the per-utterance frame counts and the padded tails are all exercised."""
+    return [int(round(float(x) * SR)) for x in np.linspace(lo_s, hi_s, batch)]
+
+
+def config2_ragged_batch(batch: int = 32, first: int = 0):
+    """The utterances of ``config2_batch`` (same seed-1000 stream) cut to ``config2_ragged_lengths``; zero-padded to 20 s."""
+    lens = config2_ragged_lengths(batch)
+    return synth.synth_audio(batch, max(lens) / SR, seed=1000, index0=first, lengths=lens)
+
+
 def config4_durations(n_utts: int = 1024) -> np.ndarray:
     return np.random.RandomState(1234).uniform(5.0, 20.0, size=n_utts)
 

@@ -55,7 +55,10 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".h", ".hip")):
                 src = open(os.path.join(dirpath, f), encoding="utf-8").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
-                assert "ref_shim" not in src, f
+                assert "ref_shim" not in src and "build_ref" not in src and "oracle/_ref" not in src and "_ref" + os.sep not in src, f
+    # ... nor ships any reference bytecode of its own: oracle/_ref is the only place the reference's modules live
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gigaam_amd")):
+        assert "_ref" not in dirpath.split(os.sep)
 
 
 def test_load_model_errors_and_api(tmp_path):

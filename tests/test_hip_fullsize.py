@@ -182,9 +182,8 @@ def test_fullsize_config5_longform_chunks_match_reference():
 def test_fullsize_config2_whole_batch_matches_reference():
     """The WHOLE timed batch of BASELINE config 2: all 32 utterances of 20 s through the REFERENCE's 16-layer
     modules as one batch of 32 (tests/golden/make_fullsize32_golden.py).  Encoder probe of every utterance <= 2e-4; ids + frames
-    bit-exact for every utterance whose smallest reference top-1 / top-2 margin exceeds 5e-4 (2.5x the encoder bar: a frame
-    closer to a tie than that can legitimately fall either way between two fp32 summation orders); the others are reported with
-    their margin -- and must still agree on all but the near-tie frames (edit distance <= 2)."""
+    bit-exact for ALL 32 utterances (r04 allowed an edit distance of 2 on the 7 utterances whose smallest reference top-1 / top-2
+    margin is below 5e-4 and measured 32 / 32; the escape hatch is gone -- the margins still go to the report)."""
     import json
     import os
 
@@ -211,11 +210,8 @@ def test_fullsize_config2_whole_batch_matches_reference():
     report("fullsize32_vs_reference", err=err, tol=2e-4, utterances_identical=f"{sum(same)}/32",
            margins_of_differing=[round(m, 6) for m, s in zip(margins, same) if not s], min_margin=min(margins))
     assert err < 2e-4, err
+    # measured since r04: 32 / 32 bit-exact, near-tie utterances included -- assert what is measured; a
+    # future regression on a 2e-5-margin frame fails loudly here and is then judged with its margin in hand
     for i, (g, r, m) in enumerate(zip(got, ref, margins)):
-        if m > 5e-4:
-            assert g == r, (i, m)
-        else:   # within arithmetic noise of a tie somewhere: everything but that frame must still agree
-            import difflib
-            sm = difflib.SequenceMatcher(a=g[0], b=r[0], autojunk=False)
-            assert sum(max(i2 - i1, j2 - j1) for tag, i1, i2, j1, j2 in sm.get_opcodes() if tag != "equal") <= 2, (i, m)
+        assert g == r, (i, "reference min margin", m)
     assert sum(1 for m in margins if m > 5e-4) >= 24      # the fixture is not vacuous

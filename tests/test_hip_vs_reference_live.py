@@ -1,0 +1,277 @@
+"""GPU: the HIP path against the REFERENCE'S OWN MODULES run live on the host beside it.
+
+The committed fixtures replay 18 fixed cases; here the reference's unmodified ``ConformerEncoder`` / ``CTCHead`` /
+``RNNTHead`` / ``CTCGreedyDecoding`` / ``RNNTGreedyDecoding`` (``oracle/_ref``: bytecode of /root/reference/gigaam/*.py made by
+``oracle/build_ref.py``; the source tree itself in the build container) run on the host CPU on shapes NO fixture holds --
+tile-edge encoder lengths T' in {1, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257}, batches of 1 / 2 / 5 / 33 in
+arbitrary length order, all model families (v1 rel-pos, v2, v3; CTC V = 34 / 257; RNN-T V = 34 / 1025) -- and on one ragged
+16-layer batch each of BASELINE configs 2 / 3 (``linspace(10 s, 20 s, 32)``) and 4 (32 x U(5, 20) s, V = 1025).
+
+Bars: encoder activations <= TOL_ENC on valid frames; CTC log-probs <= 1e-3; ids + frames BIT-EXACT for every utterance
+whose smallest reference top-1 / top-2 margin exceeds 5e-4 (a random-weight head has near-ties; such an utterance is
+reported and must still agree up to the tied frames), and the test fails if fewer than 3/4 of the utterances were checked
+exactly.  Features come from the oracle's log-mel for the encoder comparison (row a1 is carved out: no torchaudio here) and
+from the HIP frontend for the whole-path comparison.  Measured errors go to $GAM_TEST_REPORT.
+"""
+import difflib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import TOL_ENC, TOL_LOGP, oracle_features, ragged_from_device, report, valid_mask
+from oracle import gigaam_oracle as O
+from oracle import ref_shim
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not ref_shim.reference_available(),
+                                 reason="oracle/_ref missing (python oracle/build_ref.py in the build container) and no /root/reference")]
+
+EDGES = [1, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257]
+NEAR_TIE = 5e-4
+# (model, blank bias of the synthetic RNN-T joint: the blank-dominant regime of tests/golden/cases.py)
+FAMILIES = [("v1_ctc", None), ("v2_ctc", None), ("v3_ctc", None), ("v3_e2e_ctc", None),
+            ("v1_rnnt", 14.0), ("v2_rnnt", 13.5), ("v3_e2e_rnnt", 14.0)]
+# encoder lengths per batch: B = 1 (no attention mask in the reference, encoder.py:620-624), 2, 5, 33 (arbitrary order)
+BATCHES = {
+    "b1_t1": [1], "b1_t17": [17], "b1_t129": [129],
+    "b2_t16_15": [16, 15], "b2_t64_257": [64, 257],
+    "b5": [128, 127, 65, 63, 1],
+    "b33": [EDGES[(7 * i + 3) % len(EDGES)] for i in range(33)],
+}
+
+
+def _wav_len_for(cfg, t_enc: int) -> int:
+    """Smallest sample count whose encoder length (preprocess.py:78-92 -> encoder.py:77-90) is ``t_enc``."""
+    fp = O.frontend_params(cfg["preprocessor"])
+    e = cfg["encoder"]
+    stages = int(np.log2(e["subsampling_factor"]))
+    lo = (fp["n_fft"] // 2 + 1) if fp["center"] else fp["win_length"]      # reflect padding needs L > n_fft / 2
+    for n in range(lo, 16000 * 60, 40):
+        t = int(O.calc_output_length(O.feat_out_len(torch.tensor([n]), fp), e["subs_kernel_size"], stages)[0])
+        if t == t_enc:
+            return n
+        if t > t_enc:
+            break
+    raise AssertionError(f"no waveform length gives T' = {t_enc}")
+
+
+def _engine(ck):
+    from gigaam_amd.engine import HipEngine, build_config
+    cfg = ck["cfg"]
+    return HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], cfg.get("head")), ck["state_dict"], torch.device("cuda:0"))
+
+
+def _ref_decode_with_margins(ref, enc, elen, is_rnnt):
+    """The reference's decode of a batch + each utterance's smallest top-1 / top-2 log-prob margin (CTC: from its head's
+    log-probs over the valid frames; RNN-T: every joint evaluation of its own greedy loop, one utterance at a time)."""
+    dec = ref.decoding.decode(ref.head, enc, elen)
+    margins = []
+    if not is_rnnt:
+        lp = ref.head(enc)
+        t2 = lp.topk(2, dim=-1).values
+        mg = (t2[..., 0] - t2[..., 1]).masked_fill(~valid_mask(lp.shape[1], elen), float("inf"))
+        margins = mg.min(dim=1).values.tolist()
+        return [(list(i), list(f)) for _, i, f in dec], margins, lp
+    orig = ref.head.joint.joint
+    for i in range(enc.shape[0]):
+        rec = []
+
+        def spy(f, g, rec=rec):
+            out = orig(f, g)
+            t2 = out.reshape(-1, out.shape[-1]).topk(2, dim=-1).values
+            rec.append(float((t2[:, 0] - t2[:, 1]).min()))
+            return out
+        ref.head.joint.joint = spy
+        try:
+            n = int(elen[i])
+            r1 = ref.decoding.decode(ref.head, enc[i:i + 1, :, :n].contiguous(), elen[i:i + 1])
+        finally:
+            del ref.head.joint.joint
+        assert r1[0][1] == dec[i][1] and r1[0][2] == dec[i][2]       # the reference's own batched == single
+        margins.append(min(rec) if rec else float("inf"))
+    return [(list(i), list(f)) for _, i, f in dec], margins, None
+
+
+def _edit(a, b):
+    sm = difflib.SequenceMatcher(a=a, b=b, autojunk=False)
+    return sum(max(i2 - i1, j2 - j1) for tag, i1, i2, j1, j2 in sm.get_opcodes() if tag != "equal")
+
+
+def _compare_decodes(tag, got, want, margins, min_exact_frac=0.75):
+    exact = 0
+    near = []
+    for i, (g, w, m) in enumerate(zip(got, want, margins)):
+        if m > NEAR_TIE:
+            assert g == w, (tag, i, m, g[0][:12], w[0][:12])
+            exact += 1
+        else:
+            near.append((i, round(m, 7), g == w))
+            assert _edit(g[0], w[0]) <= 2, (tag, i, m)
+    assert exact >= int(min_exact_frac * len(want)), (tag, "too many near-tie utterances for a meaningful check", near)
+    return exact, near
+
+
+def _live_check(name, ck, wav, wlen, eng=None, probe=None):
+    """Run the reference on the host and the HIP path on the GPU over the same audio; assert the bars; return measurements."""
+    cfg = ck["cfg"]
+    is_rnnt = "RNNT" in cfg["decoding"]["_target_"]
+    ms = cfg["decoding"].get("max_symbols_per_step", 10)
+    ref = ref_shim.reference_model(ck)
+    eng = eng or _engine(ck)
+    feat_o, flen_o = oracle_features(ck, wav, wlen)
+    with torch.inference_mode():
+        enc_r, elen_r = ref.encoder(feat_o, flen_o)
+        want, margins, lp_r = _ref_decode_with_margins(ref, enc_r, elen_r, is_rnnt)
+    # (1) encoder on identical features
+    enc, elen = eng.encode(feat_o, flen_o)
+    assert elen.dtype == torch.int32 and elen.cpu().tolist() == elen_r.tolist()
+    assert tuple(enc.shape) == tuple(enc_r.shape) and bool(torch.isfinite(enc).all())
+    vm = valid_mask(enc.shape[2], elen_r)
+    e_enc = float(((enc.cpu() - enc_r) * vm[:, None, :]).abs().max())
+    assert e_enc < TOL_ENC, (name, e_enc)
+    # (2) the decoder ALONE on the reference's own encoder output: same input, so only a head near-tie may differ
+    if is_rnnt:
+        got_alone = ragged_from_device(*eng.rnnt_greedy(enc_r, elen_r, ms)[:3])
+    else:
+        got_alone = ragged_from_device(*eng.ctc_greedy(enc_r, elen_r))
+        lp = eng.ctc_head(enc_r).cpu()
+        e_lp = float(((lp - lp_r) * vm[:, :, None]).abs().max())
+        assert e_lp < TOL_LOGP, (name, e_lp)
+    n_alone, near_alone = _compare_decodes(name + ":decoder-alone", got_alone, want, margins)
+    # (3) whole path wav -> ids through the HIP frontend
+    enc2, elen2 = eng.encode(*eng.frontend(wav, wlen))
+    assert elen2.cpu().tolist() == elen_r.tolist()
+    e_enc2 = float(((enc2.cpu() - enc_r) * vm[:, None, :]).abs().max())
+    got = ragged_from_device(*(eng.rnnt_greedy(enc2, elen2, ms)[:3] if is_rnnt else eng.ctc_greedy(enc2, elen2)))
+    n_whole, near_whole = _compare_decodes(name + ":whole-path", got, want, margins)
+    out = dict(case=name, utterances=len(want), enc_err=e_enc, enc_err_whole_path=e_enc2, tol=TOL_ENC,
+               exact_decoder_alone=n_alone, exact_whole_path=n_whole, near_tie_utterances=near_whole,
+               min_margin=float(min(margins)), tokens=sum(len(w[0]) for w in want))
+    report("live_vs_reference", **out)
+    return out
+
+
+@pytest.mark.parametrize("batch", list(BATCHES))
+@pytest.mark.parametrize("model,bias", FAMILIES)
+def test_tile_edge_shapes_against_live_reference(model, bias, batch):
+    from gigaam_amd import synth
+    ck = synth.make_checkpoint(model, seed=1, n_layers=2, rnnt_blank_bias=bias)
+    t_encs = BATCHES[batch]
+    lens = [_wav_len_for(ck["cfg"], t) for t in t_encs]
+    wav, wlen = synth.synth_audio(len(lens), max(lens) / 16000.0, seed=900 + len(lens) + t_encs[0], lengths=lens)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    # near-tie utterances are rare but a 1-frame utterance has nothing else: one exactly-checked utterance is the floor there
+    out = _live_check(f"{model}/{batch}", ck, wav, wlen)
+    assert out["tokens"] > 0 or max(t_encs) <= 1, "degenerate decode (nothing emitted)"
+
+
+def test_rotary_table_edge_5000_frames():
+    """T' = 5000 = pos_emb_max_len (encoder.py:521,546-548): the last row of the rotary table, one 200 s utterance."""
+    from gigaam_amd import synth
+    ck = synth.make_checkpoint("v2_ctc", seed=3, n_layers=2)
+    n = _wav_len_for(ck["cfg"], 5000)
+    wav, wlen = synth.synth_audio(1, n / 16000.0, seed=77, lengths=[n])
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    _live_check("v2_ctc/T5000", ck, wav, wlen)
+
+
+def _ragged_fullsize(name, model, bias, wav, wlen):
+    from gigaam_amd import synth
+    ck = synth.make_checkpoint(model, seed=0, rnnt_blank_bias=bias)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    return _live_check(name, ck, wav, wlen)
+
+
+def _blank_bias(model):
+    import json
+    from common import ROOT
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "fullsize_meta.json")))[f"fullsize_{model}"]["blank_bias"]
+
+
+def test_fullsize_ragged_config2_linspace_against_live_reference():
+    """BASELINE config 2, SURVEY §8d's second run: v2_ctc, 16 layers, 32 utterances of linspace(10 s, 20 s, 32)."""
+    from gigaam_amd import workloads
+    wav, wlen = workloads.config2_ragged_batch(32)
+    out = _ragged_fullsize("fullsize/config2_linspace", "v2_ctc", None, wav, wlen)
+    assert out["utterances"] == 32
+
+
+def test_fullsize_ragged_config3_linspace_against_live_reference():
+    """BASELINE config 3 on the same ragged audio: v2_rnnt, 16 layers, blank-dominant head (the bias bench.py uses)."""
+    from gigaam_amd import workloads
+    wav, wlen = workloads.config2_ragged_batch(32)
+    out = _ragged_fullsize("fullsize/config3_linspace", "v2_rnnt", _blank_bias("v2_rnnt"), wav, wlen)
+    assert out["utterances"] == 32
+
+
+def test_fullsize_ragged_config4_against_live_reference():
+    """BASELINE config 4: v3_e2e_rnnt (V = 1025), 16 layers, one REAL batch of the 1024-utterance set -- batch 16 of the 32
+    length-sorted ones (durations around 12.5 s; the committed fixture holds 4 utterances of batch 0, all 499-500 frames)."""
+    from gigaam_amd import workloads
+    wav, wlen, _ = workloads.config4_batches(n_utts=1024, batch=32, only_batches=[16])[0]
+    out = _ragged_fullsize("fullsize/config4_batch16", "v3_e2e_rnnt", _blank_bias("v3_e2e_rnnt"), wav, wlen)
+    assert out["utterances"] == 32
+
+
+def test_onnx_twin_decoders_agree_with_the_hip_decoders():
+    """The reference's torch-free statements of a11 / a14 (gigaam/onnx_utils.py:39-54,73-161, MAX_LETTERS_PER_FRAME = 3 :19) as a
+    second cross-check: ``_decode_ctc_batch`` fed the argmax of the HIP head's log-probs must give gam_ctc_greedy's text, and
+    ``_decode_rnnt_batch`` DRIVEN through the HIP per-step entry points (gam_rnnt_predict / gam_rnnt_joint standing in for its two
+    ORT sessions) must give gam_rnnt_greedy's ids at max_symbols = 3."""
+    from gigaam_amd import synth
+    twins = ref_shim.import_onnx_twins()
+    ref = ref_shim.import_reference()
+    # --- a11
+    ck = synth.make_checkpoint("v2_ctc", seed=3, n_layers=2)
+    wav, wlen = synth.synth_audio(3, 4.0, seed=41, lengths=[64000, 30000, 47001])
+    eng = _engine(ck)
+    enc, elen = eng.encode(*eng.frontend(wav, wlen))
+    tok = ref.decoding.Tokenizer(ck["cfg"]["decoding"]["vocabulary"])
+    labels = eng.ctc_head(enc).argmax(-1).cpu().numpy()
+    texts = twins._decode_ctc_batch(labels, elen.cpu().numpy(), tok)
+    got = ragged_from_device(*eng.ctc_greedy(enc, elen))
+    assert texts == [tok.decode(i) for i, _ in got] and sum(len(i) for i, _ in got) > 0
+    # --- a14
+    ck = synth.make_checkpoint("v2_rnnt", seed=3, n_layers=2, rnnt_blank_bias=9.0)     # several symbols on some frames: the cap of 3 binds
+    eng = _engine(ck)
+    enc, elen = eng.encode(*eng.frontend(wav, wlen))
+    tok = ref.decoding.Tokenizer(ck["cfg"]["decoding"]["vocabulary"])
+
+    class _Node:
+        def __init__(self, name, type_="tensor(float)"):
+            self.name, self.type = name, type_
+
+    class PredSession:       # inputs (labels [b,1] i64, h [L,b,H], c [L,b,H]) -> (g [b,1,H], h', c')  (decoder.py:122-137)
+        def get_inputs(self):
+            return [_Node("x", "tensor(int64)"), _Node("h"), _Node("c")]
+
+        def get_outputs(self):
+            return [_Node("dec"), _Node("h_out"), _Node("c_out")]
+
+        def run(self, _names, feed):
+            x, h, c = (torch.from_numpy(np.ascontiguousarray(feed[k])) for k in ("x", "h", "c"))
+            g, (h2, c2) = eng.rnnt_predict(x[:, 0].cuda(), (h.cuda(), c.cuda()))
+            return [g.unsqueeze(1).cpu().numpy(), h2.cpu().numpy(), c2.cpu().numpy()]
+
+    class JointSession:      # inputs (enc [b,D,1], dec [b,H,1]) -> log-probs [b,1,1,V]  (decoder.py:74-75)
+        def get_inputs(self):
+            return [_Node("enc"), _Node("dec")]
+
+        def get_outputs(self):
+            return [_Node("joint")]
+
+        def run(self, _names, feed):
+            f = torch.from_numpy(np.ascontiguousarray(feed["enc"])).cuda().transpose(1, 2).contiguous()
+            g = torch.from_numpy(np.ascontiguousarray(feed["dec"])).cuda().transpose(1, 2).contiguous()
+            return [eng.rnnt_joint(f, g).cpu().numpy()]
+
+    cfg = ref_shim.AttrDict(ck["cfg"])
+    texts = twins._decode_rnnt_batch(enc.cpu().numpy(), elen.cpu().numpy(), cfg, [None, PredSession(), JointSession()], tok)
+    ids, frames, counts = eng.rnnt_greedy(enc, elen, twins.MAX_LETTERS_PER_FRAME)[:3]
+    got = ragged_from_device(ids, frames, counts)
+    assert texts == [tok.decode(i) for i, _ in got]
+    from collections import Counter
+    assert max(max(Counter(f).values()) for _, f in got if f) == twins.MAX_LETTERS_PER_FRAME, "the cap never bound: vacuous"
+    report("onnx_twins", ctc_tokens=int(sum(len(t) for t in texts)), rnnt_tokens=int(sum(len(i) for i, _ in got)))

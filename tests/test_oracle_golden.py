@@ -168,3 +168,88 @@ def test_frontend_against_independent_scipy_stft():
         strong = ref_t >= ref_t.max(dim=1, keepdim=True).values - 60.0 * 0.2302585   # see tests/common.py
         d = (feat.double() - ref_t).abs()
         assert float((d * strong).max()) < 5e-4 and float((d * ~strong).max()) < 2e-2
+
+
+# ----------------------------------------------------------------------------- oracle/_ref: the reference itself, travelling
+def _run_py(code, **env):
+    import os
+    import subprocess
+    import sys
+    from common import ROOT
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def test_reference_bytecode_reproduces_the_committed_goldens():
+    """oracle/_ref (CPython bytecode of /root/reference/gigaam/*.py, oracle/build_ref.py) imported WITHOUT the source tree
+    (GIGAAM_REF_FORCE_BYTECODE=1: what the GPU box sees) must BE the reference: its GigaAMASR.forward + decoding.decode on the
+    cases' seeded checkpoints reproduces the committed reference outputs (encoder <= 2e-5: the only difference is the stand-in
+    MelSpectrogram's |X|.abs().pow(2) vs the oracle's re^2 + im^2 in the features; ids + frames exact)."""
+    import os
+    from common import ROOT
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "BUILT.json")):
+        pytest.skip("oracle/_ref not built (python oracle/build_ref.py needs /root/reference)")
+    out = _run_py(r"""
+import json, sys, numpy as np, torch
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+from common import load_case, split_ragged, valid_mask
+from oracle import ref_shim
+assert ref_shim.reference_kind() == "bytecode", ref_shim.reference_kind()
+res = {}
+torch.set_num_threads(8)
+for case in ("v2_ctc_l2", "v1_ctc_l2", "v3_e2e_rnnt_l2", "v2_rnnt_l2_lstm2"):
+    ck, wav, wlen, gold = load_case(case)
+    m = ref_shim.reference_model(ck)
+    assert type(m).__module__ == "gigaam.model" and m.encoder.__class__.__module__ == "gigaam.encoder"
+    with torch.inference_mode():
+        enc, elen = m.forward(wav, wlen)
+        dec = m.decoding.decode(m.head, enc, elen)
+    vm = valid_mask(enc.shape[2], elen)[:, None, :]
+    err = float(((enc - torch.from_numpy(gold["encoded"])) * vm).abs().max())
+    want = split_ragged(gold["ids"], gold["frames"], gold["counts"].tolist())
+    res[case] = [err, [(list(i), list(f)) for _, i, f in dec] == want]
+import gigaam
+res["origin"] = gigaam.__file__
+print(json.dumps(res))
+""", GIGAAM_REF_FORCE_BYTECODE="1")
+    import json
+    res = json.loads(out.strip().splitlines()[-1])
+    assert res.pop("origin").endswith(os.path.join("oracle", "_ref", "gigaam", "__init__.pyc"))
+    for case, (err, same) in res.items():
+        assert err < 2e-5 and same, (case, err, same)
+
+
+def test_reference_manifest_matches_the_tree_it_was_built_from():
+    """oracle/ref_manifest.json (committed) = sha256 of every reference source oracle/_ref was compiled from; where the
+    reference tree is present (the build container) the files themselves must still hash to it."""
+    import hashlib
+    import json
+    import os
+    from common import ROOT
+    man = json.load(open(os.path.join(ROOT, "oracle", "ref_manifest.json")))
+    assert {"gigaam/encoder.py", "gigaam/decoder.py", "gigaam/decoding.py", "gigaam/model.py", "gigaam/preprocess.py",
+            "gigaam/utils.py", "gigaam/onnx_utils.py"} <= set(man)
+    built = os.path.join(ROOT, "oracle", "_ref", "BUILT.json")
+    if os.path.exists(built):
+        assert json.load(open(built))["sources_sha256"] == man
+    from oracle import ref_shim
+    if os.path.isdir(os.path.join(ref_shim.REFERENCE_ROOT, "gigaam")):
+        for rel, h in man.items():
+            assert hashlib.sha256(open(os.path.join(ref_shim.REFERENCE_ROOT, rel), "rb").read()).hexdigest() == h, rel
+
+
+def test_onnx_twin_ctc_decoder_agrees_with_the_oracle():
+    """gigaam/onnx_utils.py:39-54 (the reference's numpy statement of a11) on the golden log-probs == the golden ids."""
+    from oracle import ref_shim
+    if not ref_shim.reference_available():
+        pytest.skip("no reference (oracle/_ref not built)")
+    twins = ref_shim.import_onnx_twins()
+    ref = ref_shim.import_reference()
+    for case in ("v2_ctc_l2", "v3_e2e_ctc_l2"):
+        ck, wav, wlen, gold = load_case(case)
+        tok = ref.decoding.Tokenizer(ck["cfg"]["decoding"]["vocabulary"])
+        texts = twins._decode_ctc_batch(gold["log_probs"].argmax(-1), gold["enc_len"], tok)
+        want = split_ragged(gold["ids"], gold["frames"], gold["counts"].tolist())
+        assert texts == [tok.decode(i) for i, _ in want]
