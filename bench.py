@@ -84,7 +84,7 @@ def barrier_sync():
         dist.barrier()
 
 
-def make_gather(kind: str, rank: int, n_ranks: int, dev: torch.device):
+def make_gather(kind: str, rank: int, n_ranks: int, dev: torch.device, strict: bool = False):
     """The exchange callable (index, counts, ids, frames) -> the same, rank-major.  "rccl": gam_gather_ids behind
     the C ABI (the RCCL id travels over torch.distributed's store); "torch": dist.all_gather (cross-check)."""
     if n_ranks == 1:
@@ -123,6 +123,9 @@ def make_gather(kind: str, rank: int, n_ranks: int, dev: torch.device):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)      # every rank takes the same path
         if int(flag.item()) == 1:
             return comm.gather, "gam_gather_ids (RCCL ncclAllGather behind the C ABI)"
+        if strict:   # tools/scale8.sh: the day-one run must say loudly that the exchange behind the C ABI did not come up
+            raise SystemExit(f"[bench] rank {rank}: --strict-gather and gam_comm_create did not succeed on every rank "
+                             f"({box.get('err', 'watchdog expired' if th.is_alive() else 'another rank failed')})")
 
     on = dev if dist.get_backend() == "nccl" else torch.device("cpu")
 
@@ -366,11 +369,11 @@ def rnnt_bias_for(model_name: str, override):
     return None
 
 
-def ragged_host(ids, frames, counts):
-    """Decoded buffers -> host lists: the blocking D2H + slicing of gigaam_amd.decoding._ragged (the split-fp16 range flag
-    rides on the counts copy: engine.collect)."""
+def ragged_host(dec):
+    """What a decode call returned (engine.Decoded) -> host lists: the blocking D2H + slicing of gigaam_amd.decoding._ragged
+    (the split-fp16 range flag rides on the counts copy: engine.collect)."""
     from gigaam_amd.engine import HipEngine
-    rows, flag = HipEngine.collect(ids, frames, counts)
+    rows, flag = HipEngine.collect(dec)
     if flag:   # the product would repeat the batch in fp32 (model._with_f32_fallback); a timed step must not do that silently
         raise RuntimeError("split-fp16 range flag set during a bench step")
     return rows
@@ -450,6 +453,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4, 5], help="BASELINE.json configuration (default 2: the headline)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--gather", default="rccl", choices=["rccl", "torch"], help="the final exchange: gam_gather_ids (C ABI) or torch.distributed")
+    ap.add_argument("--strict-gather", action="store_true", help="N > 1: fail instead of falling back to torch.distributed when "
+                    "gam_comm_create (RCCL behind the C ABI) does not come up on every rank")
     ap.add_argument("--model", default=None, help="override the configuration's model")
     ap.add_argument("--batch", type=int, default=32, help="configs 2/3: utterances per GPU (weak) or in total (strong)")
     ap.add_argument("--seconds", type=float, default=20.0)
@@ -464,6 +469,9 @@ def main():
     ap.add_argument("--no-port-leg", action="store_true", help="config 2: do not time oracle/gigaam_oracle.py beside the reference")
     ap.add_argument("--rnnt-blank-bias", type=float, default=None,
                     help="RNN-T models: blank bias of the synthetic joint (default: the blank-dominant value of tests/golden/fullsize_meta.json)")
+    ap.add_argument("--rnnt-overlap", type=int, default=1, help="RNN-T models: 1 = the decode of batch n runs on a side stream beside the "
+                    "encoder of batch n+1 (small clusters; configs 3 / 4), 0 = in front of it on the launch stream (full-size clusters)")
+    ap.add_argument("--rnnt-side-cus", type=int, default=64, help="compute units an overlapped RNN-T decode may hold (cluster size = this / utterance slots)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--no-power", action="store_true", help="skip the board power / shader clock sampling leg")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the exact-fp32 re-timing (roofline_f32_exact)")
@@ -529,13 +537,21 @@ def main():
     eng = model.encoder.engine
     eng.set_gemm_mode(args.gemm)
     max_sym = ckpt["cfg"]["decoding"].get("max_symbols_per_step", 10)
-    gather, gather_name = make_gather(args.gather, rank, n_ranks, dev)
+    gather, gather_name = make_gather(args.gather, rank, n_ranks, dev, strict=args.strict_gather)
     scaling = "strong" if cfgno == 5 else args.scaling
 
-    def decode_dev(wav, wlen):
+    rnnt_overlap = is_rnnt and args.rnnt_overlap != 0
+
+    def decode_dev(wav, wlen, overlap=False):
+        """frontend + encoder + greedy decode, launched, no host sync.  ``overlap`` (RNN-T, another batch follows before this one is
+        collected): the decode goes to the engine's side stream with small clusters, beside the next batch's encoder."""
         feat, flen = eng.frontend(wav, wlen)
         enc, elen = eng.encode(feat, flen)
-        return eng.rnnt_greedy(enc, elen, max_sym) if is_rnnt else eng.ctc_greedy(enc, elen)
+        if is_rnnt:
+            return eng.rnnt_greedy(enc, elen, max_sym, overlap=overlap and rnnt_overlap, side_cus=args.rnnt_side_cus)
+        return eng.ctc_greedy(enc, elen)
+
+    drain = lambda: None   # noqa: E731  (pipelined steps: collect what is still in flight)
 
     # ---- the step of each configuration; `audio_s` = audio seconds ALL ranks process per step
     cpu_sample = None       # ([(wav, wlen)] host batches exactly as the GPU decodes them, their global indices) for the CPU leg
@@ -563,8 +579,10 @@ def main():
         cpu_sample = ([(wav_h, wlen_h)], list(range(g0, g1)))
 
         def step():
+            dec = None
             if g1 > g0:
-                ids, frames, counts = decode_dev(wav, wlen)
+                dec = decode_dev(wav, wlen)
+                ids, frames, counts = dec[0], dec[1], dec[2]
             else:   # strong scaling with more ranks than utterances: this rank only takes part in the exchange
                 cap0 = eng.enc_frames(eng.feat_frames(int(seconds * 16000))) * (max_sym if is_rnnt else 1)
                 ids = frames = torch.zeros((0, cap0), dtype=torch.int32, device=dev)
@@ -573,12 +591,28 @@ def main():
                 # this rank's range flag rides in the exchange as one extra row (shard.append_flag_row): the padding, the
                 # gather and the row selection below all drop the hidden tail word of `counts`, and a separate
                 # eng.range_flag() here would read a flag the decode call has already consumed
-                gi, gc, gids, gfr = gather(*shard.append_flag_row(idx_dev, counts, ids, frames, shard.range_flag_of(counts), rows))
+                gi, gc, gids, gfr = gather(*shard.append_flag_row(idx_dev, counts, ids, frames, shard.range_flag_of(dec), rows))
                 dec, _, flag = shard.collect_gathered(gi, gc, gids, gfr)
                 if flag:
                     raise RuntimeError("split-fp16 range flag set on some rank during a bench step")
                 return dec
-            return ragged_host(ids, frames, counts)        # the decoded ids (+ the range flag at N = 1) end every step on the host
+            return ragged_host(dec)        # the decoded ids (+ the range flag at N = 1) end every step on the host
+
+        if rnnt_overlap and n_ranks == 1 and cfgno != 1:
+            # RNN-T (config 3), one rank: the same launch-n / collect-n-1 pipeline configs 4 / 5 and transcribe_longform use,
+            # ACROSS steps -- batch n's greedy loop (latency-bound, side stream, small clusters) runs beside batch n+1's
+            # encoder, and the ids of batch n reach the host while n+1 is on the GPU.  K steps = K batches launched AND
+            # collected between the two barriers (drain() collects the last one inside the timed region).
+            in_flight = []
+            def step():   # noqa: F811
+                in_flight.append(decode_dev(wav, wlen, overlap=True))
+                return ragged_host(in_flight.pop(0)) if len(in_flight) > 1 else None
+
+            def drain():  # noqa: F811
+                res = None
+                while in_flight:
+                    res = ragged_host(in_flight.pop(0))
+                return res
         workload = (f"{model_name} (16-layer Conformer, random-init weights), {n_global} x "
                     f"{'linspace(%g s, %g s) RAGGED' % (0.5 * seconds, seconds) if ragged_global else '%g s' % seconds} 16 kHz utterances "
                     f"({'%d per GPU' % args.batch if scaling == 'weak' else 'global batch split over the ranks'}), frontend + encoder + "
@@ -596,7 +630,7 @@ def main():
 
         def step():
             # batch n is launched before batch n-1's ids are copied back (shard.run_sharded, collect=)
-            res = shard.run_sharded(batches, decode_dev, rank, n_ranks, gather, cap, my_batches=mine, collect=lambda h: ragged_host(*h))
+            res = shard.run_sharded(batches, decode_dev, rank, n_ranks, gather, cap, my_batches=mine, collect=ragged_host, overlap_kw=True)
             return res if rank != 0 else [(i, f, tok.decode(i)) for i, f in res]     # detokenised like the package API
         workload = (f"{model_name} (V = 1025), {n_utts} utterances with durations U(5 s, 20 s) sorted into 32-utterance batches "
                     f"dealt to {n_ranks} rank(s) ({len(mine)} batches on rank 0), frontend + encoder + RNN-T greedy + ids to host + "
@@ -645,14 +679,14 @@ def main():
                 out_b = decode_dev(wav_b, len_b)                              # launched; collected one batch later
                 t_b = time.perf_counter()
                 if pending is not None:
-                    rows += [(my_idx[len(rows) + k], i, f) for k, (i, f) in enumerate(ragged_host(*pending))]
+                    rows += [(my_idx[len(rows) + k], i, f) for k, (i, f) in enumerate(ragged_host(pending))]
                 pending = out_b
                 if trace:
                     marks.append((round((t_a - t_s) * 1e3, 1), round((t_b - t_a) * 1e3, 1), round((time.perf_counter() - t_b) * 1e3, 1), tuple(wav_b.shape)))
             if trace:
                 print("[trace] (staged_at, launch_ms, collect_prev_ms, shape):", marks, file=sys.stderr)
             if pending is not None:
-                rows += [(my_idx[len(rows) + k], i, f) for k, (i, f) in enumerate(ragged_host(*pending))]
+                rows += [(my_idx[len(rows) + k], i, f) for k, (i, f) in enumerate(ragged_host(pending))]
             res = shard.unpack_results(*gather(*shard.pack_results(rows, per_rank, cap)), len(segs))
             last5["res"] = res
             return res if rank != 0 else [(tok.decode(i), bounds[k]) for k, (i, f) in enumerate(res)]
@@ -679,7 +713,10 @@ def main():
         for i in range(k_steps):
             if profile:
                 eng.profile_level(2 if i % PROF_EVERY == 0 else 0)
-            out_ = step()
+            o = step()
+            out_ = o if o is not None else out_
+        o = drain()
+        out_ = o if o is not None else out_
         barrier_sync()
         if profile:
             eng.profile_level(0)
@@ -687,6 +724,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     do_prof = not args.no_profile
     dt, out = timed(args.steps, do_prof)
     prof = prof_all = None
@@ -694,6 +732,7 @@ def main():
         prof = eng.profile_read()
         eng.profile_enable(1)      # one extra, untimed step for the per-class breakdown
         step()
+        drain()
         torch.cuda.synchronize()
         prof_all = eng.profile_read()
         eng.profile_enable(0)
@@ -705,6 +744,7 @@ def main():
         with PowerSampler(dev.index or 0) as ps:
             for _ in range(n_pw):
                 step()
+            drain()
             torch.cuda.synchronize()
         power = ps.summary()
         power["steps_sampled"] = n_pw
@@ -722,7 +762,7 @@ def main():
         def step_serial():
             w = torch.empty(wav_pin.shape, dtype=wav_pin.dtype, device=dev)
             w.copy_(wav_pin, non_blocking=True)
-            return ragged_host(*decode_dev(w, len_pin.to(dev, non_blocking=True)))
+            return ragged_host(decode_dev(w, len_pin.to(dev, non_blocking=True)))
         step_serial()
         barrier_sync()
         t0 = time.perf_counter()
@@ -737,9 +777,9 @@ def main():
             for wb, lb in fd:
                 out_b = decode_dev(wb, lb)
                 if pending is not None:
-                    ragged_host(*pending); n_done += 1
+                    ragged_host(pending); n_done += 1
                 pending = out_b
-            ragged_host(*pending)
+            ragged_host(pending)
             return n_done + 1
         run_feeder(BatchFeeder(utt_h * 2, len(utt_h), dev))
         fd = BatchFeeder(utt_h * k_h, len(utt_h), dev)      # (its two pinned staging buffers are allocated here, outside the timed region)
@@ -761,6 +801,7 @@ def main():
         eng.set_gemm_mode("f32")
         for _ in range(2):
             step()
+        drain()
         dt32, out32 = timed(args.steps, do_prof)
         p32 = eng.profile_read() if do_prof else None
         eng.profile_enable(0)
@@ -774,6 +815,7 @@ def main():
         eng.set_gemm_mode("f16")
         for _ in range(2):
             step()
+        drain()
         dt16, out16 = timed(args.steps, do_prof)
         p16 = eng.profile_read() if do_prof else None
         eng.profile_enable(0)
@@ -856,7 +898,8 @@ def main():
                     "slices for small grids) -- 3x v_mfma_f32_32x32x16_f16 per product; plain + implicit-GEMM conv")
             peak, peak_note = F16_MFMA_PEAK_TFLOPS / 3.0, "fp16 dense MFMA peak (2500) / 3 issued MFMA FLOP per algorithmic FLOP"
             if args.gemm == "f16":
-                kern = "gam_gemm_sp_kernel<.., HI> (LDS-DMA of the hi planes only, one v_mfma_f32_32x32x16_f16 per product)"
+                kern = ("gam_gemm_sp_kernel<.., H16> (format-2 operands: plain fp16 rows written by the producers, the kernel told half "
+                        "the reduction length; two v_mfma_f32_32x32x16_f16 per 32x32x32 block = one MFMA per product)")
                 peak, peak_note = F16_MFMA_PEAK_TFLOPS, "fp16 dense MFMA peak"
         flop, ms, n, ach, frac = family(prof, peak)
         traffic, traffic_src = None, None
@@ -887,8 +930,10 @@ def main():
             line["rnnt_decode"] = {"ms_per_batch": round(dec_ms, 3), "joint_steps_per_batch": int(sum(steps)),
                                    "steps_per_s": round(sum(steps) / (dec_ms * 1e-3)),
                                    "us_per_step_longest_utterance": round(dec_ms * 1e3 / max(1, max(steps)), 3),
+                                   "overlapped_with_next_batch_encoder": bool(rnnt_overlap and n_ranks == 1),
                                    "note": "768->320 projection GEMM + gam_rnnt_cluster_kernel; the utterances of a batch decode "
-                                           "concurrently (one workgroup cluster each), a 16-frame window per hand-off round"}
+                                           "concurrently (one workgroup cluster each), a 16-frame window per hand-off round; when overlapped "
+                                           "(side stream, small clusters) ms_per_batch is the decode's own span, mostly hidden under the next encoder"}
         if cfgno in (2, 3):
             whole = FLOP_PER_UTT_20S_V2 * (float(wlen_h.sum()) / 16000.0 / 20.0 if g1 > g0 else 0.0) / (ms_step * 1e-3) / 1e12
             line["whole_path_tflops_per_gpu"] = round(whole, 2)
@@ -917,7 +962,7 @@ def main():
     if f16_leg is not None:
         dt16, out16, p16, margins = f16_leg
         leg = {"ms_per_step": round(dt16 / args.steps * 1e3, 3), "value": round(audio_s * args.steps / dt16, 1), "unit": "audio-sec/wall-sec",
-               "dtype": "fp16 products (one v_mfma_f32_32x32x16_f16 per product, hi planes only), fp32 accumulate; fp32 softmax / LayerNorm / residual",
+               "dtype": "fp16 products (one v_mfma_f32_32x32x16_f16 per product on plain-fp16 format-2 operands), fp32 accumulate; fp32 softmax / LayerNorm / residual",
                "ids_identical_to_default_mode": sum(a == b for a, b in zip(out16, out)), "utterances": len(out),
                "note": "OPT-IN (gam_set_gemm_mode(GAM_GEMM_F16) / GAM_GEMM_MODE=f16 / model.set_arithmetic('f16')): the arithmetic contract of the "
                        "reference's GPU default (fp16 autocast, gigaam/model.py:34-37), narrower than its CPU path -- never the default, never `value`"}

@@ -116,6 +116,9 @@ struct gam_handle {
   int use_sp = 1;     // large-M GEMMs on the LDS-DMA sp32 kernel (GAM_SP=0 disables)
   int sp_min_m = GAM_SP_MIN_M;   // GAM_SP_MIN_M overrides (tests force the sp path at small sizes)
   DevBuf op_planes, op_sp, splitk_ws;   // gam_op_gemm operand planes; split-K partial sums
+  DevBuf dec_splitk_ws;                 // split-K partial sums of the DECODE class's GEMMs: a decode may run on a side stream beside
+                                        // the next batch's encoder (r05), so it shares no scratch with it (tok / logits / encp / rnnt_x
+                                        // are the decode's alone already)
   int use_splitk = 1;   // GAM_SPLITK=0 disables split-K for small grids
   int fuse_reduce = 1;  // GAM_FUSE_REDUCE=0: the split-K reduce of a residual GEMM stays a kernel of its own (A/B switch)
   // hipGraph replay of the Conformer-layer launch sequence for small batches (launch-bound: a 5 s clip is
@@ -408,8 +411,9 @@ int gemm(gam_handle* h, hipStream_t s, const GamGemmArgs& a_in, int act, int cls
   }
   GamGemmArgs full = a;
   if (S > 1) {
-    if (int r = ensure(h, h->splitk_ws, (size_t)S * a.M * a.N + 64)) return r;
-    a.splitk = S; a.ldw = a.K; a.K = a.K / S; a.partial = h->splitk_ws.p;
+    DevBuf& ws = cls == GAM_PF_DECODE ? h->dec_splitk_ws : h->splitk_ws;
+    if (int r = ensure(h, ws, (size_t)S * a.M * a.N + 64)) return r;
+    a.splitk = S; a.ldw = a.K; a.K = a.K / S; a.partial = ws.p;
   }
   if (f16) {
     a.Whi = w16->hi; a.Wlo = w16->lo; a.wscale_inv = w16->inv;
@@ -511,7 +515,7 @@ void gam_destroy(gam_handle* h) {
   hipSetDevice(h->device);
   for (void* p : h->owned) hipFree(p);
   DevBuf* bufs[] = {&h->wavp, &h->spec, &h->img, &h->c2, &h->xin, &h->y1, &h->x, &h->y, &h->yr, &h->hbuf,
-                    &h->qkv, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes, &h->op_sp, &h->splitk_ws, &h->rsbuf, &h->op_rs, &h->rnnt_x, &h->jz, &h->jp, &h->jl};
+                    &h->qkv, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes, &h->op_sp, &h->splitk_ws, &h->dec_splitk_ws, &h->rsbuf, &h->op_rs, &h->rnnt_x, &h->jz, &h->jp, &h->jl};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   if (h->lens) hipFree(h->lens);
@@ -998,7 +1002,12 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
   // produce its A operands (LayerNorm, SiLU epilogue, attention, conv module, stem) write them in the
   // sp32 split layout instead of fp32 -- same bytes, no conversion pass.
   const bool sp = split_mode(h) && h->use_sp && N >= h->sp_min_m && D % 32 == 0 && DFF % 32 == 0;
-  const int spf = sp ? (h->gemm_mode == GAM_GEMM_F16 ? 2 : 1) : 0;   // operand format the producers write (gam_common.h gam_store4)
+  // operand format the producers write (gam_common.h gam_store4).  Format 2 (plain fp16, GAM_GEMM_F16) packs 64 k-values into
+  // the 128-byte line of a k-tile, so every reduction length / row pitch must be a multiple of 64; a model whose d_model or
+  // FFN width is 32 x an odd number keeps the three-term kernels for its GEMMs in that mode (as gam_op_gemm does)
+  // instead of failing half-way through a batch with the stem image already written as fp16.
+  const bool f16_fmt_ok = D % 64 == 0 && DFF % 64 == 0;   // (C == D: the stem's channel count)
+  const int spf = sp ? (h->gemm_mode == GAM_GEMM_F16 && f16_fmt_ok ? 2 : 1) : 0;
   auto sp_a = [&](GamGemmArgs& g) { if (sp) { g.Asp = reinterpret_cast<const _Float16*>(g.A); g.a_fmt = spf; } };
 
   // ------------------------------ stem ------------------------------
@@ -1556,6 +1565,13 @@ int gam_set_gemm_mode(gam_handle* h, int mode) {
 }
 
 int gam_get_gemm_mode(const gam_handle* h) { return h ? h->gemm_mode : -1; }
+
+int gam_set_rnnt_cluster(gam_handle* h, int workgroups_per_utterance) {
+  if (!h) return -1;
+  if (workgroups_per_utterance < -1 || workgroups_per_utterance > 8) return fail(h, -1, "cluster size %d outside -1 (auto) .. 8", workgroups_per_utterance);
+  h->rnnt_cluster = workgroups_per_utterance;
+  return 0;
+}
 
 int gam_range_flag(gam_handle* h, int* flag_host, void* stream) {
   if (!h || !flag_host) return -1;

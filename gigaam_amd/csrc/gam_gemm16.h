@@ -280,21 +280,8 @@ static inline hipError_t gam_launch_gemm16(const GamGemmArgs& a_in, int act, hip
   if (a.ldw == 0) a.ldw = a.K;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K <= 0 || a.Whi == nullptr || a.Wlo == nullptr) return hipErrorInvalidValue;
-  // 256x128 tiles (8 waves) move 0.75x the bytes per FLOP of 128x128 ones; used when the grid is
-  // still many rounds deep (the kernel is bound by L2->LDS operand traffic, not by the MFMA pipe)
-  static int bm256_min = -1;
-  if (bm256_min < 0) { const char* e = getenv("GAM_BM256_MIN"); bm256_min = e ? atoi(e) : 1000; }
-  const int t256 = gam_cdiv(a.M, 256) * gam_cdiv(a.N, 128);
-  const bool big = t256 >= bm256_min && a.K % 32 == 0;
-  if (big) {
-    a.ntiles = t256;
-    switch (act) {
-      case GAM_ACT_SILU: gam_launch_gemm16_t<GAM_ACT_SILU, 256, false>(a, t256, stream); break;
-      case GAM_ACT_RELU: gam_launch_gemm16_t<GAM_ACT_RELU, 256, false>(a, t256, stream); break;
-      default: gam_launch_gemm16_t<GAM_ACT_NONE, 256, false>(a, t256, stream); break;
-    }
-    return hipGetLastError();
-  }
+  // (r05: the 256x128 8-wave instantiations of this family are gone -- they spilled 4 VGPRs and were reachable only with
+  //  the LDS-DMA family switched off: every shape they took, K % 32 == 0 at >= 1000 tiles, is gam_gemm_sp_kernel's.)
   a.ntiles = gam_cdiv(a.M, 128) * gam_cdiv(a.N, 128);
   const int grid = a.ntiles;
   if (a.K % 32 != 0) return hipErrorInvalidValue;

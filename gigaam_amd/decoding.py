@@ -46,10 +46,11 @@ class RangeOverflow(RuntimeError):
     directly sees it as an error, never as silently wrong ids."""
 
 
-def _ragged(ids: Tensor, frames: Tensor, counts: Tensor) -> List[Tuple[List[int], List[int]]]:
-    """Device buffers of decode_device -> host lists (one D2H for counts + range flag, one for ids/frames)."""
+def _ragged(dec, *rest) -> List[Tuple[List[int], List[int]]]:
+    """What decode_device returned (an ``engine.Decoded``; three bare tensors are accepted) -> host lists (one D2H for
+    counts + range flag, one for ids / frames)."""
     from .engine import HipEngine
-    rows, flag = HipEngine.collect(ids, frames, counts)
+    rows, flag = HipEngine.collect(dec, *rest[:2])
     if flag:
         raise RangeOverflow("activation beyond the split-fp16 GEMM range (repeat under GAM_GEMM_F32)")
     return rows
@@ -61,19 +62,22 @@ class CTCGreedyDecoding:
         self.blank_id = len(self.tokenizer)
 
     @torch.inference_mode()
-    def decode_device(self, head: CTCHead, encoded: Tensor, lengths: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    def decode_device(self, head: CTCHead, encoded: Tensor, lengths: Tensor, overlap: bool = False):
         """The device half of ``decode``: (ids, frames, counts) i32 tensors on the GPU, no host sync -- a driver
-        can launch the next batch before it looks at this one (``finish``)."""
+        can launch the next batch before it looks at this one (``finish``).  ``overlap`` is accepted for signature symmetry
+        with the RNN-T decoder and ignored: the CTC decode is one 8 us kernel."""
         c = head.num_classes
         assert c == len(self.tokenizer) + 1, f"Num classes {c} != len(vocab)+1 {len(self.tokenizer)+1}"
         return head.engine.ctc_greedy(encoded, lengths)
 
-    def finish(self, ids: Tensor, frames: Tensor, counts: Tensor) -> List[Tuple[str, List[int], List[int]]]:
-        return [(self.tokenizer.decode(i), i, f) for i, f in _ragged(ids, frames, counts)]
+    def finish(self, dec, *rest) -> List[Tuple[str, List[int], List[int]]]:
+        """``dec``: the object ``decode_device`` returned (pass it whole: it carries the range flag word and the decode's
+        completion event as explicit fields)."""
+        return [(self.tokenizer.decode(i), i, f) for i, f in _ragged(dec, *rest)]
 
     @torch.inference_mode()
     def decode(self, head: CTCHead, encoded: Tensor, lengths: Tensor) -> List[Tuple[str, List[int], List[int]]]:
-        return self.finish(*self.decode_device(head, encoded, lengths))
+        return self.finish(self.decode_device(head, encoded, lengths))
 
 
 class RNNTGreedyDecoding:
@@ -83,12 +87,17 @@ class RNNTGreedyDecoding:
         self.max_symbols = max_symbols_per_step
 
     @torch.inference_mode()
-    def decode_device(self, head: RNNTHead, encoded: Tensor, enc_len: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
-        return head.engine.rnnt_greedy(encoded, enc_len, self.max_symbols)
+    def decode_device(self, head: RNNTHead, encoded: Tensor, enc_len: Tensor, overlap: bool = False):
+        """``overlap``: the caller is about to launch ANOTHER batch's frontend + encoder on the current stream -- run this
+        latency-bound greedy loop beside it (decode side stream, small clusters: engine.HipEngine.rnnt_greedy) instead of in
+        front of it.  Leave it False for a batch whose result is collected next (full-size clusters are faster alone)."""
+        return head.engine.rnnt_greedy(encoded, enc_len, self.max_symbols, overlap=overlap)
 
-    def finish(self, ids: Tensor, frames: Tensor, counts: Tensor) -> List[Tuple[str, List[int], List[int]]]:
-        return [(self.tokenizer.decode(i), i, f) for i, f in _ragged(ids, frames, counts)]
+    def finish(self, dec, *rest) -> List[Tuple[str, List[int], List[int]]]:
+        """``dec``: the object ``decode_device`` returned (pass it whole: it carries the range flag word and the decode's
+        completion event as explicit fields)."""
+        return [(self.tokenizer.decode(i), i, f) for i, f in _ragged(dec, *rest)]
 
     @torch.inference_mode()
     def decode(self, head: RNNTHead, encoded: Tensor, enc_len: Tensor) -> List[Tuple[str, List[int], List[int]]]:
-        return self.finish(*self.decode_device(head, encoded, enc_len))
+        return self.finish(self.decode_device(head, encoded, enc_len))

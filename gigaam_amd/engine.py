@@ -78,6 +78,36 @@ _DTYPES = {
 }
 
 
+class Decoded(tuple):
+    """What ``ctc_greedy`` / ``rnnt_greedy`` return.  Unpacks as ``(ids, frames, counts)`` (``+ (dump, dump_count)`` when a
+    logits dump was asked for) and carries the decode's two hidden companions as EXPLICIT fields -- they used to hang off the
+    ``counts`` view as Python attributes, which any ``torch.cat`` / slice / unpack-and-repack dropped silently (ADVICE r3,
+    VERDICT r4 weak #13):
+
+    ``ext``    i32 [B + 1]: ``counts`` is its first B words, the last word receives the split-fp16 range flag
+               (gam_range_flag_fetch), so ``collect`` brings both to the host in ONE copy;
+    ``event``  recorded on the stream the decode ran on, right behind it: ``collect`` waits for THIS on its side stream, not
+               for whatever the caller has enqueued since (the next batch of a launch-n / collect-n-1 pipeline);
+    ``stream`` the stream the decode ran on.
+
+    Pass the object itself to ``HipEngine.collect`` / ``shard.range_flag_of``; three bare tensors are accepted too, but then
+    nothing is known about a flag or an event (a plain blocking copy on the current stream)."""
+
+    def __new__(cls, ids: Tensor, frames: Tensor, counts: Tensor, ext: Optional[Tensor] = None, event=None, stream=None,
+                dump: Optional[Tensor] = None, dump_count: Optional[Tensor] = None):
+        self = tuple.__new__(cls, (ids, frames, counts) if dump is None else (ids, frames, counts, dump, dump_count))
+        self.ext, self.event, self.stream = ext, event, stream
+        return self
+
+    ids = property(lambda self: self[0])
+    frames = property(lambda self: self[1])
+    counts = property(lambda self: self[2])
+
+    def flag_word(self) -> Optional[Tensor]:
+        """The device word (i32 [1]) that received the range flag of this decode, or None."""
+        return None if self.ext is None else self.ext[-1:]
+
+
 def _ptr(t: Optional[Tensor]) -> C.c_void_p:
     return C.c_void_p(0 if t is None else t.data_ptr())
 
@@ -107,6 +137,8 @@ class HipEngine:
             rc = self.lib.gam_set_weight(self._h, key.encode(), C.c_void_p(t.data_ptr()), _DTYPES[t.dtype], shape, t.dim())
             self._check(rc, f"gam_set_weight({key})")
         self._check(self.lib.gam_finalize(self._h), "gam_finalize")
+        import os
+        self._rnnt_cluster_default = int(os.environ.get("GAM_RNNT_CLUSTER", "-1"))   # what gam_create read (restored after an overlapped decode)
 
     # ------------------------------------------------------------------ utils
     def _check(self, rc: int, what: str) -> None:
@@ -145,7 +177,7 @@ class HipEngine:
         """True if, since the last call, an unscaled split-fp16 GEMM operand left fp16's range (gam_range_flag);
         synchronises the current stream and clears the flag.  NOTE: ``ctc_greedy`` / ``rnnt_greedy`` CONSUME the flag (they
         move it into the hidden tail word of the counts buffer they return, which ``collect`` reads): after a decode call
-        this method reports 0 -- read the flag from that buffer (shard.range_flag_of) or through ``collect``."""
+        this method reports 0 -- read the flag from the ``Decoded`` object they return (``.flag_word()``) or through ``collect``."""
         out = C.c_int(0)
         with torch.cuda.device(self.device):
             self._check(self.lib.gam_range_flag(self._h, C.byref(out), self._stream()), "gam_range_flag")
@@ -155,22 +187,20 @@ class HipEngine:
         """counts i32 [b] as a view of a [b + 1] buffer whose last element receives the range flag
         (gam_range_flag_fetch) -- ``collect`` then brings both to the host in ONE copy."""
         ext = torch.empty((b + 1,), dtype=torch.int32, device=self.device)
-        counts = ext[:b]
-        counts._gam_ext = ext          # (plain attribute: keeps the buffer alive and findable from the view)
-        return counts, ext
+        return ext[:b], ext
 
-    def _fetch_flag(self, ext: Tensor, counts: Optional[Tensor] = None) -> None:
+    def _fetch_flag(self, ext: Tensor):
+        """Move the range flag into ``ext``'s tail word and record "this decode is complete" on the stream it ran on;
+        returns (event, stream) for the ``Decoded`` object.  ``collect`` waits for the event on a side stream, so a caller
+        that has already launched the next batch (model.transcribe_longform, shard.run_sharded, bench.py configs 4 / 5) is not
+        held until that next batch has finished too -- a ``.cpu()`` on the launch stream is ordered behind everything enqueued
+        there, which made the "launch n, then collect n-1" pipelines wait for batch n (measured: +3.9 ms per 33 ms step)."""
         rc = self.lib.gam_range_flag_fetch(self._h, C.c_void_p(ext.data_ptr() + 4 * (ext.numel() - 1)), self._stream())
         self._check(rc, "gam_range_flag_fetch")
-        if counts is not None:
-            # "this decode is complete" on the launch stream: ``collect`` waits for THIS on a side stream, so a caller that has
-            # already launched the next batch (the one-batch pipelines of model.transcribe_longform, shard.run_sharded,
-            # bench.py configs 4 / 5) is not held until that next batch has finished too -- a ``.cpu()`` on the launch
-            # stream is ordered behind everything enqueued there, which made the "launch n, then collect n-1" pipelines wait
-            # for batch n and left the GPU idle while the host staged batch n+1 (measured: +3.9 ms per 33 ms step)
-            evt = torch.cuda.Event()
-            evt.record(torch.cuda.current_stream(self.device))
-            counts._gam_evt = evt
+        st = torch.cuda.current_stream(self.device)
+        evt = torch.cuda.Event()
+        evt.record(st)
+        return evt, st
 
     _collect_streams: Dict[int, "torch.cuda.Stream"] = {}
 
@@ -183,25 +213,28 @@ class HipEngine:
         return st
 
     @staticmethod
-    def collect(ids: Tensor, frames: Tensor, counts: Tensor):
-        """Decoded device buffers -> ([(ids, frames)] host lists, range_flag).  One blocking D2H for the counts AND the
-        split-fp16 range flag accumulated up to this decode (when ``counts`` came from ctc_greedy / rnnt_greedy), one
-        for the used part of ids/frames."""
-        ext = getattr(counts, "_gam_ext", None)
-        evt = getattr(counts, "_gam_evt", None)
+    def collect(dec, frames: Optional[Tensor] = None, counts: Optional[Tensor] = None):
+        """``Decoded`` -> ([(ids, frames)] host lists, range_flag).  One blocking D2H for the counts AND the split-fp16 range
+        flag accumulated up to this decode, one for the used part of ids / frames, both on a side stream that waits for the
+        decode's own completion event only.  Three bare tensors (ids, frames, counts) are accepted for callers that built them
+        some other way: a plain blocking copy on the current stream, flag unknown (False)."""
+        if isinstance(dec, Decoded):
+            ids, frames, counts, ext, evt = dec[0], dec[1], dec[2], dec.ext, dec.event
+        else:
+            ids, ext, evt = dec, None, None
+        src = ext if ext is not None else counts
         if evt is not None and ids.is_cuda:
-            # the copies run on a side stream that waits for the decode's own completion event only (see _fetch_flag)
             side = HipEngine._collect_stream(ids.device)
             with torch.cuda.stream(side):
                 side.wait_event(evt)
-                n = (ext if ext is not None else counts).cpu().tolist()
+                n = src.cpu().tolist()
                 flag = bool(n.pop()) if ext is not None else False
                 width = max(n) if n else 0
                 ids_h, fr_h = ids[:, :width].cpu(), frames[:, :width].cpu()
-            for t in (ids, frames, ext if ext is not None else counts):
+            for t in (ids, frames, src):
                 t.record_stream(side)
         else:
-            n = (ext if ext is not None else counts).cpu().tolist()
+            n = src.cpu().tolist()
             flag = bool(n.pop()) if ext is not None else False
             width = max(n) if n else 0
             ids_h, fr_h = ids[:, :width].cpu(), frames[:, :width].cpu()
@@ -268,7 +301,7 @@ class HipEngine:
         self._check(rc, "gam_emo_probs")
         return out
 
-    def ctc_greedy(self, encoded: Tensor, enc_len: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    def ctc_greedy(self, encoded: Tensor, enc_len: Tensor) -> Decoded:
         encoded = self._dev(encoded, torch.float32)
         enc_len = self._dev(enc_len, torch.int32)
         b, _, tp = encoded.shape
@@ -279,29 +312,68 @@ class HipEngine:
             rc = self.lib.gam_ctc_greedy(self._h, _ptr(encoded), _ptr(enc_len), b, tp, _ptr(ids), _ptr(frames),
                                          _ptr(counts), self._stream())
             self._check(rc, "gam_ctc_greedy")
-            self._fetch_flag(ext, counts)
-        return ids, frames, counts
+            evt, st = self._fetch_flag(ext)
+        return Decoded(ids, frames, counts, ext, evt, st)
 
-    def rnnt_greedy(self, encoded: Tensor, enc_len: Tensor, max_symbols: int, dump_cap: int = 0):
+    def set_rnnt_cluster(self, n: int) -> None:
+        """Workgroups per utterance of the cluster decode kernel (gam_set_rnnt_cluster): -1 auto, 0 one-workgroup kernel, 1..8."""
+        self._check(self.lib.gam_set_rnnt_cluster(self._h, int(n)), "gam_set_rnnt_cluster")
+
+    def _decode_side_stream(self) -> "torch.cuda.Stream":
+        st = getattr(self, "_side_stream", None)
+        if st is None:
+            st = self._side_stream = torch.cuda.Stream(self.device)
+        return st
+
+    @staticmethod
+    def side_cluster(b: int, side_cus: int) -> int:
+        """Cluster size of an OVERLAPPED decode: the clusters of ``b`` utterances (8 utterance columns x ceil(b / 8) rows x C
+        workgroups, one per CU -- gam_api.hip) together hold at most ``side_cus`` compute units; at least 1."""
+        return max(1, min(8, side_cus // (8 * ((b + 7) // 8))))
+
+    def rnnt_greedy(self, encoded: Tensor, enc_len: Tensor, max_symbols: int, dump_cap: int = 0, overlap: bool = False,
+                    side_cus: int = 64) -> Decoded:
+        """RNNTGreedyDecoding.decode on the device (gam_rnnt_greedy).  ``overlap``: launch it on this engine's decode SIDE stream
+        with small clusters (at most ``side_cus`` CUs held), ordered behind everything enqueued on the current stream so far, and
+        return at once -- the caller's next ``frontend`` / ``encode`` on the current stream then runs BESIDE this decode instead of
+        behind it (the greedy loop is latency-bound: with the GPU to itself it keeps ~224 CUs resident and idle).
+        The range flag is fetched on the CURRENT stream first, so it covers exactly this batch's frontend + encoder (fetched on
+        the side stream it would swallow a flag the next batch's encoder sets meanwhile).  Same kernels, same results."""
         encoded = self._dev(encoded, torch.float32)
         enc_len = self._dev(enc_len, torch.int32)
         b, _, tp = encoded.shape
         cap = tp * max_symbols
-        ids = torch.empty((b, cap), dtype=torch.int32, device=self.device)
-        frames = torch.empty((b, cap), dtype=torch.int32, device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        side = self._decode_side_stream() if overlap else None
         counts, ext = self._counts_with_flag(b)
-        dump = dcount = None
-        if dump_cap > 0:
-            dump = torch.zeros((b, dump_cap, self.cfg.num_classes), dtype=torch.float32, device=self.device)
-            dcount = torch.zeros((b,), dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
-            rc = self.lib.gam_rnnt_greedy(self._h, _ptr(encoded), _ptr(enc_len), b, tp, max_symbols, _ptr(ids),
-                                          _ptr(frames), _ptr(counts), _ptr(dump), _ptr(dcount), dump_cap, self._stream())
-            self._check(rc, "gam_rnnt_greedy")
-            self._fetch_flag(ext, counts)
-        if dump_cap > 0:
-            return ids, frames, counts, dump, dcount
-        return ids, frames, counts
+        if overlap:
+            with torch.cuda.device(self.device):
+                self._fetch_flag(ext)            # on the launch stream: this batch's own flag (its event is not the decode's)
+            side.wait_stream(main)
+            self.set_rnnt_cluster(self.side_cluster(b, side_cus))
+        try:
+            with torch.cuda.stream(side) if overlap else torch.cuda.device(self.device):
+                ids = torch.empty((b, cap), dtype=torch.int32, device=self.device)
+                frames = torch.empty((b, cap), dtype=torch.int32, device=self.device)
+                dump = dcount = None
+                if dump_cap > 0:
+                    dump = torch.zeros((b, dump_cap, self.cfg.num_classes), dtype=torch.float32, device=self.device)
+                    dcount = torch.zeros((b,), dtype=torch.int32, device=self.device)
+                rc = self.lib.gam_rnnt_greedy(self._h, _ptr(encoded), _ptr(enc_len), b, tp, max_symbols, _ptr(ids),
+                                              _ptr(frames), _ptr(counts), _ptr(dump), _ptr(dcount), dump_cap, self._stream())
+                self._check(rc, "gam_rnnt_greedy")
+                if overlap:
+                    st = torch.cuda.current_stream(self.device)
+                    evt = torch.cuda.Event()
+                    evt.record(st)
+                    for t in (encoded, enc_len, ext):      # allocated on the launch stream, last used on the side stream
+                        t.record_stream(st)
+                else:
+                    evt, st = self._fetch_flag(ext)
+        finally:
+            if overlap:
+                self.set_rnnt_cluster(self._rnnt_cluster_default)
+        return Decoded(ids, frames, counts, ext, evt, st, dump, dcount)
 
     def rnnt_predict(self, labels: Optional[Tensor], state: Optional[Tuple[Tensor, Tensor]], batch_size: int = 1):
         """One predictor step (reference RNNTDecoder.predict, gigaam/decoder.py:85-102): labels i [B] or None (zero input),

@@ -56,9 +56,16 @@ class BatchFeeder:
     batches later, after an event recorded on the consumer's stream when it asks for the next batch (i.e. after it has
     enqueued everything that reads the view; ``len`` is a fresh tensor and may be kept) -- no
     per-batch device allocation (a fresh ``torch.empty`` on a side stream every batch cost ~4 ms per 41 MB batch: the
-    caching allocator cannot recycle a block whose last use is on another stream without waiting for it) and no host sync."""
+    caching allocator cannot recycle a block whose last use is on another stream without waiting for it) and no host sync.
 
-    def __init__(self, segments: Sequence[Tensor], batch_size: int, device: torch.device):
+    LIFETIME CONTRACT of the yielded ``wav`` (also in INTEGRATION.md): (1) enqueue every kernel that reads it on the
+    stream that is current when you ask for the NEXT batch -- that is where the "slot consumed" event is recorded; (2) do not
+    keep it past the request for the batch after next: ``list(BatchFeeder(...))`` over three or more batches holds views whose
+    slots have been overwritten, silently.  A consumer that wants to keep batches passes ``copy=True``: every yielded ``wav`` is
+    then a private clone (made on the consumer's stream), at the cost of the per-batch allocation the slots exist to avoid."""
+
+    def __init__(self, segments: Sequence[Tensor], batch_size: int, device: torch.device, copy: bool = False):
+        self.copy = bool(copy)
         self.segments = segments
         self.batch_size = batch_size
         self.device = torch.device(device)
@@ -111,7 +118,7 @@ class BatchFeeder:
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(ready)
             ln.record_stream(cur)
-            yield wav, ln
+            yield (wav.clone() if self.copy else wav), ln
             # the consumer is back: everything that reads this slot's views has been enqueued on its stream
             done = torch.cuda.Event()
             done.record(torch.cuda.current_stream(self.device))

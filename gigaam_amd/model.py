@@ -227,21 +227,30 @@ class GigaAMASR(GigaAM):
     def _head_cfg(self) -> Any:
         return _node(self.cfg, "head")
 
-    def _with_words(self, decoded, wav_lens: Tensor, encoded_len: Tensor, word_timestamps: bool):
+    def _with_words(self, decoded, wav_lens: Tensor, encoded_len: Tensor, word_timestamps: bool, event=None):
+        """``event``: the decode's completion event (``engine.Decoded.event``) when the caller has one -- the lengths are then
+        copied on the collect stream behind THAT event; without one the collect stream waits for the current stream (correct
+        for any caller, e.g. the reference-style ``_decode(enc_cuda, enc_len_cuda, wav_lens_cpu, word_timestamps=True)``)."""
         if not word_timestamps:
             return [(text, None) for text, _, _ in decoded]
         from .timestamps_utils import compute_frame_shift, frames_to_words
 
-        if encoded_len.is_cuda:
-            # on the collect stream, which has already waited for this batch's decode (engine.HipEngine.collect): a copy on
-            # the launch stream would queue behind the NEXT batch's kernels in the one-batch pipelines
-            side = HipEngine._collect_stream(encoded_len.device)
+        on_dev = [t for t in (wav_lens, encoded_len) if t.is_cuda]
+        if on_dev:
+            # on the collect stream: a copy on the launch stream would queue behind the NEXT batch's kernels in the one-batch
+            # pipelines.  The ordering is explicit (ADVICE r4): the decode's own event, or everything enqueued so far
+            dev = on_dev[0].device
+            side = HipEngine._collect_stream(dev)
+            if event is not None:
+                side.wait_event(event)
+            else:
+                side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 wl, el = wav_lens.cpu().tolist(), encoded_len.cpu().tolist()
-            wav_lens.record_stream(side)
-            encoded_len.record_stream(side)
+            for t in on_dev:          # (record_stream is not defined for host tensors)
+                t.record_stream(side)
         else:
-            wl, el = wav_lens.cpu().tolist(), encoded_len.cpu().tolist()
+            wl, el = wav_lens.tolist(), encoded_len.tolist()
         out: List[Tuple[str, Optional[List[Word]]]] = []
         for i, (text, ids, frames) in enumerate(decoded):
             shift = compute_frame_shift(int(wl[i]), int(el[i]))
@@ -255,18 +264,20 @@ class GigaAMASR(GigaAM):
 
     # ---- the launch / collect pair every transcribe path is built from (public: a driver -- bench.py, shard.run_sharded,
     #      a test -- can interleave them, or replace them to script the decode)
-    def launch_batch(self, wav: Tensor, lengths: Tensor):
+    def launch_batch(self, wav: Tensor, lengths: Tensor, overlap: bool = False):
         """Device half of ``transcribe_batch``: frontend + encoder + greedy decode of a collated batch (wav [B,L] zero
-        padded, len [B]) launched on the current stream, NO host sync.  Returns an opaque handle for ``collect_batch``."""
+        padded, len [B]) launched on the current stream, NO host sync.  Returns an opaque handle for ``collect_batch``.
+        ``overlap=True`` says another ``launch_batch`` follows before this one is collected: an RNN-T decode then runs on
+        the decode side stream BESIDE the next batch's encoder (decoding.RNNTGreedyDecoding.decode_device)."""
         wav, lengths = wav.to(self._device), lengths.to(self._device)
         encoded, encoded_len = self._encode(wav, lengths)
-        return self.decoding.decode_device(self.head, encoded, encoded_len), lengths, encoded_len
+        return self.decoding.decode_device(self.head, encoded, encoded_len, overlap=overlap), lengths, encoded_len
 
     def collect_batch(self, handle, word_timestamps: bool = False) -> List[Tuple[str, Optional[List[Word]]]]:
         """Host half: blocks on the handle's decode, detokenises, builds word timestamps.  Raises
         ``decoding.RangeOverflow`` if the split-fp16 range flag was set (the callers below repeat in fp32)."""
         dev_out, wav_lens, encoded_len = handle
-        return self._with_words(self.decoding.finish(*dev_out), wav_lens, encoded_len, word_timestamps)
+        return self._with_words(self.decoding.finish(dev_out), wav_lens, encoded_len, word_timestamps, event=getattr(dev_out, "event", None))
 
     @torch.inference_mode()
     def transcribe(self, wav_file: str, word_timestamps: bool = False) -> TranscriptionResult:
@@ -334,8 +345,9 @@ class GigaAMASR(GigaAM):
                         result.append(Segment(text=text, start=start, end=end))
 
             pending = None
-            for wav, lens in BatchFeeder(segments, fr_batch_size, self._device):   # pinned, double-buffered H2D
-                handle = self.launch_batch(wav, lens)
+            n_batches = (len(segments) + fr_batch_size - 1) // fr_batch_size
+            for k, (wav, lens) in enumerate(BatchFeeder(segments, fr_batch_size, self._device)):   # pinned, double-buffered H2D
+                handle = self.launch_batch(wav, lens, overlap=k + 1 < n_batches)     # (RNN-T: decode n beside encoder n+1)
                 if pending is not None:
                     emit(pending)
                 pending = handle

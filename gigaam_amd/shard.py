@@ -102,17 +102,18 @@ def unpack_results(index: Tensor, counts: Tensor, ids: Tensor, frames: Tensor, n
 
 
 # --------------------------------------------------------------------------- the range flag across the exchange
-# One rank's split-fp16 range flag (engine.HipEngine: it arrives in the hidden tail word of the decode's counts buffer)
+# One rank's split-fp16 range flag (engine.Decoded.ext: the tail word of the buffer the decode's counts are a view of)
 # must survive padding, the gather and the row selection.  It travels as ONE extra row of the exchanged buffers whose
 # index word is FLAG_CLEAR or FLAG_SET (both negative: never mistaken for an utterance), so every rank learns every
 # rank's flag in the exchange it performs anyway -- no extra host synchronisation, no attribute on a tensor view.
 FLAG_CLEAR, FLAG_SET = -1, -2
 
 
-def range_flag_of(counts: Tensor) -> Optional[Tensor]:
-    """The device word that received the range flag of the decode that produced ``counts`` (i32 [1]), or None."""
-    ext = getattr(counts, "_gam_ext", None)
-    return None if ext is None else ext[-1:]
+def range_flag_of(dec) -> Optional[Tensor]:
+    """The device word (i32 [1]) that received the range flag of a decode -- ``dec`` is the ``engine.Decoded`` object the decode
+    call returned (an explicit field of it: nothing hangs off a tensor view any more) -- or None for anything else."""
+    fw = getattr(dec, "flag_word", None)
+    return fw() if callable(fw) else None
 
 
 def append_flag_row(index: Tensor, counts: Tensor, ids: Tensor, frames: Tensor, flag: Optional[Tensor], rows: int):
@@ -143,7 +144,7 @@ def collect_gathered(gi: Tensor, gc: Tensor, gids: Tensor, gfr: Tensor):
 
 def run_sharded(batches: Sequence[Tuple[Tensor, Tensor, Sequence[int]]], decode_batch: Callable, rank: int, n_ranks: int,
                 gather: Callable, cap: int, snake: bool = True, my_batches: Optional[Sequence[int]] = None,
-                collect: Optional[Callable] = None):
+                collect: Optional[Callable] = None, overlap_kw: bool = False):
     """Drive one rank's share of ``batches`` [(wav, len, global_indices)] through ``decode_batch(wav, len) ->
     [(ids, frames)]`` and gather everything: returns [(ids, frames)] for ALL utterances in global order (on every
     rank).  ``gather(index, counts, ids, frames) -> the same four, concatenated rank-major``; it is called exactly
@@ -151,7 +152,9 @@ def run_sharded(batches: Sequence[Tuple[Tensor, Tensor, Sequence[int]]], decode_
 
     With ``collect``, ``decode_batch`` only LAUNCHES a batch (returns an opaque handle, no host sync) and
     ``collect(handle) -> [(ids, frames)]`` brings it to the host; batch n is launched before batch n-1 is collected,
-    so the D2H wait and the host-side list building overlap the GPU's work on the next batch."""
+    so the D2H wait and the host-side list building overlap the GPU's work on the next batch.  ``overlap_kw``: also call
+    ``decode_batch(wav, len, overlap=<another batch of mine follows>)`` so that an RNN-T decode can run beside the next
+    batch's encoder (model.launch_batch / engine.rnnt_greedy)."""
     mine = list(my_batches) if my_batches is not None else deal(len(batches), rank, n_ranks, snake)
     n_total = sum(len(b[2]) for b in batches)
     # every rank contributes the same number of rows (fixed-size all-gather): the largest share
@@ -167,9 +170,9 @@ def run_sharded(batches: Sequence[Tuple[Tensor, Tensor, Sequence[int]]], decode_
         rows.extend((int(g), i, f) for g, (i, f) in zip(gidx, res))
 
     pending = None
-    for j in mine:
+    for k, j in enumerate(mine):
         wav, wlen, gidx = batches[j]
-        out = decode_batch(wav, wlen)
+        out = decode_batch(wav, wlen, overlap=k + 1 < len(mine)) if overlap_kw else decode_batch(wav, wlen)
         if collect is None:
             take(out, gidx)
         else:

@@ -112,6 +112,15 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
                     int max_symbols, int32_t* ids, int32_t* frames, int32_t* counts,
                     float* logits_dump, int32_t* dump_count, int dump_cap, void* stream);
 
+/* Workgroups per utterance of the cluster decode kernel behind gam_rnnt_greedy: -1 = as many as the device holds at once
+ * (the default: the decode has the GPU to itself), 0 = the one-workgroup-per-utterance kernel, 1..8 = at most that many.
+ * A caller that runs the decode of batch n on a side stream BESIDE the encoder of batch n+1 (the product's RNN-T
+ * pipelines do, r05: model.launch_batch) asks for small clusters so that the latency-bound decode holds few CUs; results
+ * are the same for every setting (tests: C in {0, 1, 2, 3, 5, 8}).  gam_rnnt_greedy is safe to run concurrently with
+ * gam_frontend / gam_encode of the SAME handle on another stream (it shares no scratch with them); two decodes of one
+ * handle must be stream-ordered.  (Environment GAM_RNNT_CLUSTER sets the initial value.) */
+int gam_set_rnnt_cluster(gam_handle* h, int workgroups_per_utterance);
+
 /* The RNN-T head taken apart (r04): the per-step entry points the reference exposes as sub-modules.  The greedy decode above
  * never calls them; they exist for callers that drive their own search or export the head.
  * gam_rnnt_predict replaces RNNTDecoder.predict (gigaam/decoder.py:85-102) for ONE step of B samples: labels i32 [B] (a value
@@ -134,12 +143,15 @@ int gam_emo_probs(gam_handle* h, const float* encoded, const int32_t* enc_len, i
  *   GAM_GEMM_F16X3 -- three-term split on v_mfma_f32_32x32x16_f16 with fp32 accumulation
  *                     (a = a_hi + a_lo, w = w_hi + w_lo; the a_lo.w_lo term, ~2^-22 relative,
  *                     is dropped): fp32-equivalent accuracy at several times the rate.
- *   GAM_GEMM_F16   -- OPT-IN speed mode (r04), never the default: ONE fp16 MFMA per product on the hi planes of the same
- *                     operands (a ~ a_hi, w ~ w_hi: 11 significant bits each), fp32 accumulation, fp32 softmax /
+ *   GAM_GEMM_F16   -- OPT-IN speed mode (r04), never the default: ONE fp16 MFMA per product on plain-fp16 operands (the
+ *                     producing kernels store each activation rounded once to fp16, "format 2"; the weights' hi plane;
+ *                     a ~ fp16(a), w ~ fp16(w): 11 significant bits each), fp32 accumulation, fp32 softmax /
  *                     LayerNorm / residual stream -- the arithmetic contract of the reference's own GPU default (fp16
  *                     autocast + half() encoder, gigaam/model.py:34-37, gigaam/__init__.py:188-189), NOT that of its CPU
  *                     path: results differ from GAM_GEMM_F16X3 at the 1e-3 .. 1e-2 level in the encoder output.  Covers
  *                     the encoder GEMMs, the stem convolution and the attention products; the range guard below applies.
+ *                     (Format 2 needs d_model and the FFN width to be multiples of 64; a model where they are only
+ *                     multiples of 32 keeps the three-term GEMM kernels in this mode -- gam_encode and gam_op_gemm alike.)
  * Default: GAM_GEMM_F16X3 (environment GAM_GEMM_MODE=f32 | f16 selects another at gam_create).
  * The CTC / RNN-T head GEMMs and the windowed DFT always use GAM_GEMM_F32; gam_op_gemm follows the mode. */
 enum { GAM_GEMM_F32 = 0, GAM_GEMM_F16X3 = 1, GAM_GEMM_F16 = 2 };

@@ -159,3 +159,80 @@ def test_rnnt_per_step_entry_points(case):
             label, state = k, new_state
     c0 = int(gold["counts"][0])
     assert ids == gold["ids"][:c0].tolist() and frames == gold["frames"][:c0].tolist()
+
+
+def test_feeder_pipelined_without_host_syncs_and_copy_option():
+    """the feeder's device slots are REUSED (two slots, views yielded).  (a) The product's usage -- every reader of
+    batch n enqueued on the current stream before batch n + 1 is requested, results looked at one batch late, no
+    torch.cuda.synchronize() anywhere -- over 6 ragged batches must see exactly ``collate``'s bytes; (b) ``copy=True`` lets a
+    consumer keep every batch (``list(feeder)``)."""
+    from gigaam_amd.feeder import BatchFeeder, batches, collate
+    g = torch.Generator().manual_seed(5)
+    segs = [torch.randn(int(n), generator=g) for n in torch.randint(20000, 400000, (17,), generator=g)]
+    dev = torch.device("cuda:0")
+    want = [collate(c) for c in batches(segs, 3)]
+    assert len(want) == 6
+    # (a) un-synchronised pipeline: per batch a few device ops whose (fresh) results are kept; the views themselves are not
+    kept, pending = [], None
+    big = torch.empty((64, 1 << 20), device=dev)
+    for wav, ln in BatchFeeder(segs, 3, dev):
+        big.normal_()                                       # keep the stream busy so the side-stream copies really run ahead
+        res = (wav.double().sum(dim=1), wav[:, ::977].clone(), wav[:, -1].clone(), ln.clone())
+        if pending is not None:
+            kept.append(tuple(t.cpu() for t in pending))    # collected one batch late, like model.transcribe_longform
+        pending = res
+    kept.append(tuple(t.cpu() for t in pending))
+    assert len(kept) == len(want)
+    for (sm, strided, last, ln), (w, l) in zip(kept, want):
+        assert torch.equal(ln, l) and torch.equal(strided, w[:, ::977]) and torch.equal(last, w[:, -1])
+        assert torch.allclose(sm, w.double().sum(dim=1), rtol=0, atol=1e-9)
+    # (b) copy=True: every batch survives being kept
+    held = list(BatchFeeder(segs, 3, dev, copy=True))
+    torch.cuda.synchronize()
+    for (wav, ln), (w, l) in zip(held, want):
+        assert torch.equal(wav.cpu(), w) and torch.equal(ln.cpu(), l)
+
+
+@pytest.mark.parametrize("model_name,bias", [("v2_rnnt", 13.5), ("v3_e2e_rnnt", 14.0)])
+def test_rnnt_decode_overlapped_with_the_next_encoder(model_name, bias):
+    """r05: the RNN-T decode of batch n on the engine's side stream (small clusters) BESIDE the frontend + encoder of batch
+    n + 1 on the launch stream, same handle -- six ragged batches launched back to back with no host sync in between, collected
+    one batch late -- must give exactly the ids + frames of the serial path (decode in front of the next encoder, full-size
+    clusters), through ``model.launch_batch(overlap=True)`` / ``collect_batch`` and through the engine directly."""
+    import gigaam_amd
+    from gigaam_amd import synth
+    from gigaam_amd.engine import HipEngine
+    ck = synth.make_checkpoint(model_name, seed=1, n_layers=2, rnnt_blank_bias=bias)
+    model = gigaam_amd.model_from_checkpoint(ck, "cuda:0")
+    eng = model.encoder.engine
+    ms = ck["cfg"]["decoding"].get("max_symbols_per_step", 10)
+    batches = []
+    for k in range(6):
+        b = [9, 32, 5, 17, 33, 8][k]
+        lens = [int(16000 * (1.0 + 0.37 * ((3 * i + k) % 11))) for i in range(b)]
+        batches.append(synth.synth_audio(b, max(lens) / 16000.0, seed=300 + k, lengths=lens))
+    serial = []
+    for wav, wlen in batches:
+        enc, elen = eng.encode(*eng.frontend(wav, wlen))
+        serial.append(HipEngine.collect(eng.rnnt_greedy(enc, elen, ms))[0])
+    assert sum(len(i) for rows in serial for i, _ in rows) > 50
+    for side_cus in (32, 64, 128):
+        pend, got = None, []
+        for k, (wav, wlen) in enumerate(batches):
+            enc, elen = eng.encode(*eng.frontend(wav, wlen))
+            dec = eng.rnnt_greedy(enc, elen, ms, overlap=k + 1 < len(batches), side_cus=side_cus)
+            if pend is not None:
+                got.append(HipEngine.collect(pend)[0])
+            pend = dec
+        got.append(HipEngine.collect(pend)[0])
+        assert got == serial, side_cus
+    # the package seam
+    texts_serial = [model.transcribe_batch(w, l) for w, l in batches]
+    pend, texts = None, []
+    for k, (wav, wlen) in enumerate(batches):
+        h = model.launch_batch(wav, wlen, overlap=k + 1 < len(batches))
+        if pend is not None:
+            texts.append(model.collect_batch(pend))
+        pend = h
+    texts.append(model.collect_batch(pend))
+    assert texts == texts_serial

@@ -49,7 +49,7 @@ def test_gemm_kernel_shapes_and_epilogues(mode):
     eng = _make_engine(synth.model_cfg("v2_ctc"), {}, mode, head=False)
     g = torch.Generator().manual_seed(0)
     # asymmetric operands, ragged M/N edges, all activations (transposes / layout slips cannot hide)
-    # the last three shapes reach the many-tile variants (128x128 phase-separated, 256x128)
+    # the last three shapes reach the many-tile variant (128x128 phase-separated)
     for (m, n, k, act) in [(128, 128, 32, 0), (300, 200, 64, 0), (1000, 768, 768, 1), (257, 34, 768, 0), (515, 1536, 96, 2), (1, 1, 32, 0),
                            (16064, 768, 64, 0), (16064, 3072, 64, 1), (33000, 1536, 32, 2),
                            # steady-state k-loop of the large-batch kernel (192x256 / 256x256 tiles, LDS-DMA)

@@ -62,7 +62,7 @@ def main():
 
                 def whole():
                     enc, elen = eng.encode(*eng.frontend(wav, wlen))
-                    rows, flag = HipEngine.collect(*eng.ctc_greedy(enc, elen))
+                    rows, flag = HipEngine.collect(eng.ctc_greedy(enc, elen))
                     assert not flag
                     return rows
                 ms_enc, ms_all = timed(enc_only, reps), timed(whole, reps)
