@@ -109,6 +109,7 @@ struct gam_handle {
   int rnnt_cluster = -1;        // GAM_RNNT_CLUSTER: 0 = one workgroup per utterance, N = force N per utterance, -1 = auto
   int rnnt_coop = 1;            // GAM_RNNT_COOP=0: plain instead of cooperative launch of the cluster kernel
   int rnnt_force_timeout = 0;   // GAM_RNNT_FORCE_TIMEOUT=1 (test hook): odd utterances' clusters report a failed hand-off
+  int rnnt_exclusive = 1;       // GAM_RNNT_EXCLUSIVE=0: decode workgroups ask for their own LDS size only (default: the CU's whole LDS)
   DevBuf rnnt_x;                // hand-off granules + status word of the cluster kernel
 
   // workspace (grow-only)
@@ -482,6 +483,7 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   if (const char* e = getenv("GAM_GRAPH")) h->use_graph = atoi(e);
   if (const char* e = getenv("GAM_GRAPH_MAX_ROWS")) h->graph_max_rows = atoi(e);
   if (const char* e = getenv("GAM_RNNT_CLUSTER")) h->rnnt_cluster = atoi(e);
+  if (const char* e = getenv("GAM_RNNT_EXCLUSIVE")) h->rnnt_exclusive = atoi(e);
   if (const char* e = getenv("GAM_RNNT_COOP")) h->rnnt_coop = atoi(e);
   if (const char* e = getenv("GAM_RNNT_FORCE_TIMEOUT")) h->rnnt_force_timeout = atoi(e);
   {
@@ -1342,7 +1344,8 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
     GamRnntArgs f = a;
     f.only_failed = only_failed;
     f.wout_in_lds = gam_rnnt_smem(f.H, f.JH, f.V, 1, f.L) <= 96 * 1024 ? 1 : 0;
-    const size_t sm1 = gam_rnnt_smem(f.H, f.JH, f.V, f.wout_in_lds, f.L);
+    size_t sm1 = gam_rnnt_smem(f.H, f.JH, f.V, f.wout_in_lds, f.L);
+    if (h->rnnt_exclusive && B <= h->ncu && sm1 <= 160 * 1024) sm1 = 160 * 1024;   // (owns its CU like a cluster member: see below)
     static std::atomic<unsigned long long> attr5{0}, attr8{0};
     HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_rnnt_greedy_kernel<5>), 160 * 1024, attr5));
     HIPCHK(h, gam_set_max_lds(reinterpret_cast<const void*>(gam_rnnt_greedy_kernel<8>), 160 * 1024, attr8));
@@ -1366,12 +1369,24 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
       memset(&ca, 0, sizeof ca);
       ca.a = a; ca.whh_q = h->lstm_whh_q; ca.wpred_q = h->jn_pred_q; ca.C = C;
       ca.force_dead = h->rnnt_force_timeout;
+      { const char* e = getenv("GAM_RNNT_DBG"); ca.dbg = e ? atoi(e) : 0; }
       const int nI = gam_cdiv(a.H, C), need = gam_cdiv(4 * nI, 256);
-      const int nr = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 3 ? 3 : (need <= 5 ? 5 : 8)));
+      int nr = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 3 ? 3 : (need <= 5 ? 5 : 8)));
+      if (getenv("GAM_RNNT_DBG") && (atoi(getenv("GAM_RNNT_DBG")) & 4)) nr = 8;
       const int nV = gam_cdiv(gam_cdiv(a.V, C), 16) * 16;
       ca.wout_slice_in_lds = (size_t)nV * (JH + 4) * 4 + gam_rnnt_cluster_smem(a.H, JH, a.V, C, nr, 0) <= 96 * 1024 ? 1 : 0;
+      if (ca.dbg & 2) ca.wout_slice_in_lds = 0;
+      if (ca.dbg & 8) ca.wout_slice_in_lds = 1;
       ca.wpred_slice_in_lds = gam_rnnt_cluster_smem(a.H, JH, a.V, C, nr, ca.wout_slice_in_lds, 1) <= 150 * 1024 ? 1 : 0;
-      const size_t sm = gam_rnnt_cluster_smem(a.H, JH, a.V, C, nr, ca.wout_slice_in_lds, ca.wpred_slice_in_lds);
+      size_t sm = gam_rnnt_cluster_smem(a.H, JH, a.V, C, nr, ca.wout_slice_in_lds, ca.wpred_slice_in_lds);
+      // A decode workgroup OWNS its compute unit: it asks for the CU's whole LDS (160 KB), so no other workgroup that uses LDS
+      // -- of this launch or of ANOTHER stream's kernel -- is placed beside it.  r05 finding (tools/overlap_debug*.py,
+      // profiles/r05_overlap_investigation.txt): with the decode on a side stream beside the next batch's encoder, a decode
+      // workgroup that shared its CU with a workgroup of the small-tile LDS-DMA GEMM (gam_gemm_sp_kernel, 64-96 KB of LDS:
+      // both fit) came out with a slightly perturbed predictor state in 5-30 % of the launches -- never with the GPU to
+      // itself, never beside the 112-128 KB tiles (which cannot share a CU with it), never with this line.  The grid is at
+      // most one workgroup per CU anyway (C is chosen that way), so the claim costs nothing.
+      if ((h->rnnt_exclusive || (ca.dbg & 16)) && sm <= 160 * 1024) sm = 160 * 1024;
       const size_t xg = gam_rnnt_cluster_xgranules(a.H, JH, C) * (size_t)B;
       if (sm <= 160 * 1024 && need <= 8) {
         if (int r = ensure(h, h->rnnt_x, xg * 2 + 64)) return r;   // (floats: 2 per granule) + status word
@@ -1415,6 +1430,7 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
                   resident ? " (resident)" : "", st[T_ROUNDS], st[T_GATES] / 100.0, st[T_XH] / 100.0, st[T_PRED] / 100.0, st[T_XP] / 100.0, st[T_Z] / 100.0,
                   st[T_JOINT] / 100.0, st[T_XA] / 100.0, st[T_COMB] / 100.0, st[T_CTRL] / 100.0);
         }
+        if (getenv("GAM_RNNT_NO_REPAIR")) return 0;   // debug: leave a failed cluster's counts at -1 (HipEngine.collect then raises)
         return launch_single(1);   // repair pass: no-op workgroups unless a cluster gave up
       }
     }
@@ -1565,6 +1581,23 @@ int gam_set_gemm_mode(gam_handle* h, int mode) {
 }
 
 int gam_get_gemm_mode(const gam_handle* h) { return h ? h->gemm_mode : -1; }
+
+// Debug: FNV-1a hash of one of the decode's scratch buffers as it is in device memory now (the call synchronises the device).
+// which: 0 = token-major encoder output (tok), 1 = encoder projection (encp), 2 = hand-off granules (rnnt_x), 3 = CTC logits.
+int gam_debug_buffer_hash(gam_handle* h, int which, uint64_t* hash_out, int64_t* floats_out) {
+  if (!h || !hash_out) return -1;
+  const DevBuf* b = which == 0 ? &h->tok : which == 1 ? &h->encp : which == 2 ? &h->rnnt_x : which == 3 ? &h->logits : nullptr;
+  if (!b) return fail(h, -1, "no such buffer %d", which);
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipDeviceSynchronize());
+  std::vector<uint32_t> host(b->cap);
+  if (b->cap) HIPCHK(h, hipMemcpy(host.data(), b->p, b->cap * sizeof(float), hipMemcpyDeviceToHost));
+  uint64_t x = 1469598103934665603ull;
+  for (uint32_t v : host) { x ^= v; x *= 1099511628211ull; }
+  *hash_out = x;
+  if (floats_out) *floats_out = (int64_t)b->cap;
+  return 0;
+}
 
 int gam_set_rnnt_cluster(gam_handle* h, int workgroups_per_utterance) {
   if (!h) return -1;

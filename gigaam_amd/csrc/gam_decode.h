@@ -152,6 +152,14 @@ struct GamRnntArgs {
 #define GAM_RNNT_MAXV 2048
 #define GAM_RNNT_WIN 16
 
+// 16-byte loads with the address space stated (the decode kernels hold no FLAT instruction: every pointer that may be LDS or global gets two instantiations of its loop)
+__device__ __forceinline__ f32x4 gam_rc_lds4(const float* p) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>((__attribute__((address_space(3))) const void*)(p));
+}
+__device__ __forceinline__ f32x4 gam_rc_glb4(const float* p) {
+  return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((__attribute__((address_space(1))) const void*)(p));
+}
+
 static inline size_t gam_rnnt_smem(int H, int JH, int V, int wout_in_lds, int L = 1) {
   const int vp = (V + 15) / 16 * 16;
   size_t f = (size_t)8 * H + 2 * JH + (size_t)GAM_RNNT_WIN * (JH + 4) + (size_t)GAM_RNNT_WIN * (vp + 1) + 64 + 16;
@@ -317,31 +325,35 @@ __global__ __launch_bounds__(256) void gam_rnnt_greedy_kernel(GamRnntArgs a) {
     for (int nt = wave; nt * 16 < VP; nt += 4) {
       int v = nt * 16 + li;
       const int vc = v < V ? v : V - 1;
-      // W_out rows: from the LDS copy when the whole matrix fits (char vocabularies), else L2
-      const float* wr = (wout_l != nullptr ? wout_l + (size_t)vc * WLD : a.wout + (size_t)vc * JH) + 4 * lg4;
+      // W_out rows: from the LDS copy when the whole matrix fits (char vocabularies), else L2 -- two instantiations of the
+      // loop with address-space-qualified loads, never one generic pointer (which makes every load a FLAT instruction)
       const float* zr = zw + li * ZLD + 4 * lg4;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-      for (int k0 = 0; k0 + 64 <= JH; k0 += 64) {      // 4 loads in flight per step
-        float4 wf[4];
+      auto tile = [&](auto load4, const float* wr) {
+        for (int k0 = 0; k0 + 64 <= JH; k0 += 64) {      // 4 loads in flight per step
+          f32x4 wf[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) wf[u] = *reinterpret_cast<const float4*>(wr + k0 + 16 * u);
+          for (int u = 0; u < 4; ++u) wf[u] = load4(wr + k0 + 16 * u);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float4 zf = *reinterpret_cast<const float4*>(zr + k0 + 16 * u);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.x, wf[u].x, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf[u].y, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf[u].z, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf[u].w, acc, 0, 0, 0);
+          for (int u = 0; u < 4; ++u) {
+            const f32x4 zf = gam_rc_lds4(zr + k0 + 16 * u);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.x, wf[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf[u].w, acc, 0, 0, 0);
+          }
         }
-      }
-      for (int k0 = JH / 64 * 64; k0 + 16 <= JH; k0 += 16) {
-        const float4 zf = *reinterpret_cast<const float4*>(zr + k0);
-        const float4 wf = *reinterpret_cast<const float4*>(wr + k0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.x, wf.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf.w, acc, 0, 0, 0);
-      }
+        for (int k0 = JH / 64 * 64; k0 + 16 <= JH; k0 += 16) {
+          const f32x4 zf = gam_rc_lds4(zr + k0);
+          const f32x4 wf = load4(wr + k0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.x, wf.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf.w, acc, 0, 0, 0);
+        }
+      };
+      if (wout_l != nullptr) tile([](const float* p) { return gam_rc_lds4(p); }, wout_l + (size_t)vc * WLD + 4 * lg4);
+      else tile([](const float* p) { return gam_rc_glb4(p); }, a.wout + (size_t)vc * JH + 4 * lg4);
       // C/D: col = lane&15 = class, row = 4*(lane>>4) + r = frame
       if (v < V) {
         const float bo = a.bout[v];

@@ -42,6 +42,7 @@ struct GamRnntClusterArgs {
   int wout_slice_in_lds;     // this member's class slice of W_out is cached in LDS
   int wpred_slice_in_lds;    // this member's rows of W_pred are cached in LDS ([H/4][nP][4]): the step's pp no longer waits on L2
   int force_dead;            // test hook (GAM_RNNT_FORCE_TIMEOUT=1): odd utterances report a failed hand-off without decoding
+  int dbg;                   // debug switches (GAM_RNNT_DBG): 1 = window rows by plain loads instead of LDS-DMA
 };
 
 #define GAM_RC_WIN 16
@@ -57,6 +58,9 @@ enum { T_GATES = 1, T_XH, T_PRED, T_XP, T_Z, T_JOINT, T_XA, T_COMB, T_CTRL, T_RO
 #define GAM_RC_MARK(id)
 #endif
 #define GAM_RC_TIMEOUT_TICKS 100000000LL   // wall_clock64 ticks (100 MHz): 1 s
+// "every load issued so far has landed", as a compiler barrier too: keeps a batch of independent loads TOGETHER in front of
+// their uses (hipcc otherwise sinks each load into the conditional block that consumes it: one L2 round trip per load)
+#define GAM_RC_LOADS_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 __device__ __forceinline__ void gam_rc_put(unsigned long long* p, float v, unsigned tag) {
   __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
@@ -183,6 +187,10 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       const int f = idx / JQ, q = idx - f * JQ;
       int tt = tw + (f < Wn ? f : Wn - 1);
       tt = tt < 0 ? 0 : (tt < a.Tp ? tt : a.Tp - 1);
+      if (g.dbg & 1) {
+        *reinterpret_cast<f32x4*>(zenc + c * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(a.encp + ((size_t)b * a.Tp + tt) * JH + 4 * q);
+        continue;
+      }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.encp + ((size_t)b * a.Tp + tt) * JH + 4 * q),
                                        (__attribute__((address_space(3))) void*)(zenc + c * 256), 16, 0, 0);
     }
@@ -289,8 +297,8 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
 #pragma unroll
               for (int u = 0; u < 16; ++u) {
                 const int q = q0 + u < HQ ? q0 + u : HQ - 1;
-                w[u] = wpl != nullptr ? *reinterpret_cast<const f32x4*>(wpl + ((size_t)q * nP + rr) * 4)
-                                      : *reinterpret_cast<const f32x4*>(g.wpred_q + ((size_t)q * JH + r) * 4);
+                if (wpl != nullptr) w[u] = gam_rc_lds4(wpl + ((size_t)q * nP + rr) * 4);
+                else w[u] = gam_rc_glb4(g.wpred_q + ((size_t)q * JH + r) * 4);
               }
 #pragma unroll
               for (int u = 0; u < 16; ++u)
@@ -312,8 +320,8 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
 #pragma unroll
               for (int u = 0; u < 16; ++u) {
                 const int q = q0 + u < qb ? q0 + u : qb - 1;
-                w[u] = wpl != nullptr ? *reinterpret_cast<const f32x4*>(wpl + ((size_t)q * nP + rr) * 4)
-                                      : *reinterpret_cast<const f32x4*>(g.wpred_q + ((size_t)q * JH + r) * 4);
+                if (wpl != nullptr) w[u] = gam_rc_lds4(wpl + ((size_t)q * nP + rr) * 4);
+                else w[u] = gam_rc_glb4(g.wpred_q + ((size_t)q * JH + r) * 4);
               }
 #pragma unroll
               for (int u = 0; u < 16; ++u)
@@ -369,29 +377,36 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
     for (int nt = wave; v0 + nt * 16 < v1; nt += 4) {
       const int v = v0 + nt * 16 + li;
       const int vc = v < V ? v : V - 1;
-      const float* wr = (wout_l != nullptr ? wout_l + (size_t)(vc - v0) * WLD : a.wout + (size_t)vc * JH) + 4 * lg4;
+      // The W_out slice lives either in LDS (char vocabularies at C >= 3) or in global memory: two instantiations of the loop
+      // with address-space-qualified loads (gam_rc_lds4 / gam_rc_glb4) -- one generic pointer selected at run time made every
+      // load a FLAT instruction (r05: the library now holds none).
       const float* zr = zw + li * ZLD + 4 * lg4;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc, acc2 = acc, acc3 = acc;   // (k mod 4 chains: MFMA latency, not rate, bounds one tile)
       // all of the tile's W_out reads in flight at once (JH / 16 x 16 bytes per lane): with the slice streamed from L2
       // (SentencePiece vocabularies) every batch of loads is one L2 round trip, and a wave runs several tiles
       constexpr int MAXU = GAM_RNNT_MAXH / 16, UB = RESQ > 0 ? 10 : 32;   // (register-resident W_hh leaves room for 10 at a time)
+      auto tile = [&](auto load4, const float* wr, const bool from_global) {
 #pragma unroll
-      for (int u0 = 0; u0 < MAXU; u0 += UB) {
-        if (16 * u0 + 16 > JH) break;
-        float4 wf[UB];
+        for (int u0 = 0; u0 < MAXU; u0 += UB) {
+          if (16 * u0 + 16 > JH) break;
+          f32x4 wf[UB];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) wf[u] = *reinterpret_cast<const float4*>(wr + (16 * (u0 + u) + 16 <= JH ? 16 * (u0 + u) : 0));
+          for (int u = 0; u < UB; ++u) wf[u] = load4(wr + (16 * (u0 + u) + 16 <= JH ? 16 * (u0 + u) : 0));
+          if (from_global) GAM_RC_LOADS_LANDED();      // the whole batch in flight, ONE round trip
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          if (16 * (u0 + u) + 16 <= JH) {
-            const float4 zf = *reinterpret_cast<const float4*>(zr + 16 * (u0 + u));
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.x, wf[u].x, acc, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf[u].y, acc1, 0, 0, 0);
-            acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf[u].z, acc2, 0, 0, 0);
-            acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf[u].w, acc3, 0, 0, 0);
+          for (int u = 0; u < UB; ++u) {
+            if (16 * (u0 + u) + 16 <= JH) {
+              const f32x4 zf = gam_rc_lds4(zr + 16 * (u0 + u));
+              acc = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.x, wf[u].x, acc, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.y, wf[u].y, acc1, 0, 0, 0);
+              acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.z, wf[u].z, acc2, 0, 0, 0);
+              acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(zf.w, wf[u].w, acc3, 0, 0, 0);
+            }
           }
         }
-      }
+      };
+      if (wout_l != nullptr) tile([](const float* p) { return gam_rc_lds4(p); }, wout_l + (size_t)(vc - v0) * WLD + 4 * lg4, false);
+      else tile([](const float* p) { return gam_rc_glb4(p); }, a.wout + (size_t)vc * JH + 4 * lg4, true);
       acc = (acc + acc1) + (acc2 + acc3);
       if (v < v1) {   // C/D: col = lane&15 = class, row = 4*(lane>>4) + r = frame
         const float bo = a.bout[v];
@@ -488,6 +503,13 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
           float* dp = a.dump + ((size_t)b * a.dump_cap + n_dump + f) * V;
           const float lse = lse_s[f];
           for (int vl = tid; v0 + vl < v1; vl += 256) dp[v0 + vl] = lgw[f * LLD + vl] - lse;
+          if ((g.dbg & 64) && cm == 0 && tid == 0 && V >= 12) {   // debug: internals instead of the first log-probs
+            float sh = 0.f, sp = 0.f, se = 0.f, sz = 0.f, sc = 0.f;
+            for (int k = 0; k < H; ++k) sh += h_s[k];
+            for (int k = 0; k < nI; ++k) sc += c_s[k];
+            for (int k = 0; k < JH; ++k) { sp += pp[k]; se += zenc[f * JH + k]; sz += zw[f * ZLD + k]; }
+            dp[0] = sh; dp[1] = sp; dp[2] = se; dp[3] = sz; dp[4] = (float)label; dp[5] = (float)(t + f); dp[6] = sc; dp[7] = tabv[0];
+          }
         }
       }
     }

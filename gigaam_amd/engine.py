@@ -329,6 +329,9 @@ class HipEngine:
     def side_cluster(b: int, side_cus: int) -> int:
         """Cluster size of an OVERLAPPED decode: the clusters of ``b`` utterances (8 utterance columns x ceil(b / 8) rows x C
         workgroups, one per CU -- gam_api.hip) together hold at most ``side_cus`` compute units; at least 1."""
+        import os
+        if "GAM_DEBUG_SIDE_CLUSTER" in os.environ:      # debug: force the overlapped decode's cluster size (0 = one-workgroup kernel)
+            return int(os.environ["GAM_DEBUG_SIDE_CLUSTER"])
         return max(1, min(8, side_cus // (8 * ((b + 7) // 8))))
 
     def rnnt_greedy(self, encoded: Tensor, enc_len: Tensor, max_symbols: int, dump_cap: int = 0, overlap: bool = False,

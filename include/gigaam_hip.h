@@ -121,6 +121,11 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
  * handle must be stream-ordered.  (Environment GAM_RNNT_CLUSTER sets the initial value.) */
 int gam_set_rnnt_cluster(gam_handle* h, int workgroups_per_utterance);
 
+/* Debug aid (r05): FNV-1a hash over one of the decode's scratch buffers as it sits in device memory (synchronises the
+ * device).  which: 0 = token-major copy of the encoder output, 1 = encoder projection, 2 = hand-off granules, 3 = CTC
+ * logits.  Used by tools/overlap_debug5.py to show that nothing but the decode writes these buffers. */
+int gam_debug_buffer_hash(gam_handle* h, int which, uint64_t* hash_out, int64_t* floats_out);
+
 /* The RNN-T head taken apart (r04): the per-step entry points the reference exposes as sub-modules.  The greedy decode above
  * never calls them; they exist for callers that drive their own search or export the head.
  * gam_rnnt_predict replaces RNNTDecoder.predict (gigaam/decoder.py:85-102) for ONE step of B samples: labels i32 [B] (a value
