@@ -471,7 +471,8 @@ def main():
                     help="RNN-T models: blank bias of the synthetic joint (default: the blank-dominant value of tests/golden/fullsize_meta.json)")
     ap.add_argument("--rnnt-overlap", type=int, default=1, help="RNN-T models: 1 = the decode of batch n runs on a side stream beside the "
                     "encoder of batch n+1 (small clusters; configs 3 / 4), 0 = in front of it on the launch stream (full-size clusters)")
-    ap.add_argument("--rnnt-side-cus", type=int, default=64, help="compute units an overlapped RNN-T decode may hold (cluster size = this / utterance slots)")
+    ap.add_argument("--rnnt-side-cus", type=int, default=0, help="compute units an overlapped RNN-T decode may hold (cluster size = this / utterance "
+                    "slots); 0 = the engine's choice (96 for a char vocabulary, 160 for a SentencePiece one)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--no-power", action="store_true", help="skip the board power / shader clock sampling leg")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the exact-fp32 re-timing (roofline_f32_exact)")

@@ -335,9 +335,10 @@ class HipEngine:
         return max(1, min(8, side_cus // (8 * ((b + 7) // 8))))
 
     def rnnt_greedy(self, encoded: Tensor, enc_len: Tensor, max_symbols: int, dump_cap: int = 0, overlap: bool = False,
-                    side_cus: int = 64) -> Decoded:
+                    side_cus: int = 0) -> Decoded:
         """RNNTGreedyDecoding.decode on the device (gam_rnnt_greedy).  ``overlap``: launch it on this engine's decode SIDE stream
-        with small clusters (at most ``side_cus`` CUs held), ordered behind everything enqueued on the current stream so far, and
+        with small clusters (at most ``side_cus`` CUs held; 0 = by vocabulary: 96 for a char head, 160 where W_out is streamed
+        from L2 -- measured on configs 3 / 4, profiles/r05_ab_experiments.txt), ordered behind everything enqueued on the current stream so far, and
         return at once -- the caller's next ``frontend`` / ``encode`` on the current stream then runs BESIDE this decode instead of
         behind it (the greedy loop is latency-bound: with the GPU to itself it keeps ~224 CUs resident and idle).
         The range flag is fetched on the CURRENT stream first, so it covers exactly this batch's frontend + encoder (fetched on
@@ -353,7 +354,7 @@ class HipEngine:
             with torch.cuda.device(self.device):
                 self._fetch_flag(ext)            # on the launch stream: this batch's own flag (its event is not the decode's)
             side.wait_stream(main)
-            self.set_rnnt_cluster(self.side_cluster(b, side_cus))
+            self.set_rnnt_cluster(self.side_cluster(b, side_cus if side_cus > 0 else (96 if self.cfg.num_classes <= 64 else 160)))
         try:
             with torch.cuda.stream(side) if overlap else torch.cuda.device(self.device):
                 ids = torch.empty((b, cap), dtype=torch.int32, device=self.device)
