@@ -84,6 +84,7 @@ struct GamGemmArgs {
   int c_guard;
   long long* tlog;      // instrumented builds (GAM_SP_INSTRUMENT, GAM_SP_DBG & 16): per-workgroup timeline, 8 words per tile
   int prio;             // LDS-DMA GEMM: s_setprio 1 for the later-dispatched half of the waves (GAM_SP_PRIO, A/B switch)
+  int tile_order;       // LDS-DMA GEMM: 0 = n innermost (the default), G > 0 = groups of G column tiles outermost (GAM_SP_ORDER, r05 experiment)
 };
 
 #define GAM_GEMM_BM 128

@@ -104,8 +104,18 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
   const int bid = blockIdx.x;
   const int xcd = bid & 7;
   const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int m0 = (lid / nbn) * BM;
-  const int n0 = (lid % nbn) * BN;
+  int tm = lid / nbn, tn = lid % nbn;
+  if (g.tile_order > 0 && nbn % g.tile_order == 0) {
+    // r05 experiment (GAM_SP_ORDER = G): groups of G column tiles OUTERMOST -- an XCD's contiguous share of the tile sequence
+    // then stays inside one group, i.e. G x BN rows of W (G = 3, BN = 256, K = 768: 2.4 MB, resident in the XCD's 4 MB L2)
+    // while the row tiles stream past; same tiles, same arithmetic: bit-identical results (profiles/r05_gemm_tile_order.txt)
+    const int G = g.tile_order, nbm = (g.M + BM - 1) / BM;
+    const int grp = lid / (nbm * G), rem = lid - grp * (nbm * G);
+    tm = rem / G;
+    tn = grp * G + rem % G;
+  }
+  const int m0 = tm * BM;
+  const int n0 = tn * BN;
   GAM_SP_TL(0);
 
   // ---- DMA sources.  Piece q of an operand = tile rows 8q .. 8q+7; this wave moves pieces
@@ -583,9 +593,10 @@ static inline hipError_t gam_launch_gemm_sp(const GamGemmArgs& a_in, int act, hi
   if (a.splitk <= 1) { a.splitk = 0; a.partial = nullptr; }
   const int grid = gam_cdiv(a.M, 64 * mt) * gam_cdiv(a.N, 64 * nw);
   a.ntiles = grid;
-  static const int dbg = gam_env_int_once("GAM_SP_DBG"), prio = gam_env_int_once("GAM_SP_PRIO");   // (thread-safe one-time init)
+  static const int dbg = gam_env_int_once("GAM_SP_DBG"), prio = gam_env_int_once("GAM_SP_PRIO"), order = gam_env_int_once("GAM_SP_ORDER");   // (thread-safe one-time init)
   a.dbg = dbg;
   a.prio = prio;
+  a.tile_order = order;
 #if GAM_SP_INSTRUMENT
   static long long* tl_dev = nullptr;
   static int tl_cap = 0;
