@@ -314,3 +314,38 @@ def test_gemm_plan_invariants():
     assert lib.gam_tune_sp_stages(3) == 0 and plan_ex(2008, 768, 768)[3] == 3
     assert lib.gam_tune_sp_stages(4) != 0
     assert lib.gam_tune_sp_stages(0) == 0
+
+
+def test_decoded_object_carries_flag_and_event_explicitly():
+    """r05: what a decode returns is ONE object whose hidden companions are explicit fields -- nothing hangs off
+    a tensor view any more, so a slice / cat / unpack cannot silently drop the range flag.  CPU tensors: the plain collect path."""
+    from gigaam_amd import shard
+    from gigaam_amd.engine import Decoded, HipEngine
+    ext = torch.tensor([2, 0, 3, 1], dtype=torch.int32)          # counts of 3 utterances + the flag word (set)
+    ids = torch.arange(12, dtype=torch.int32).reshape(3, 4)
+    frames = ids + 100
+    dec = Decoded(ids, frames, ext[:3], ext=ext)
+    a, b, c = dec                                                # unpacks like the old 3-tuple
+    assert a is ids and b is frames and torch.equal(c, ext[:3]) and len(dec) == 3 and dec.counts is dec[2]
+    assert not hasattr(c, "_gam_ext") and not hasattr(c, "_gam_evt")
+    assert torch.equal(dec.flag_word(), ext[-1:]) and torch.equal(shard.range_flag_of(dec), ext[-1:])
+    assert shard.range_flag_of(c) is None and shard.range_flag_of((ids, frames, c)) is None      # bare tensors know nothing
+    rows, flag = HipEngine.collect(dec)
+    assert flag is True and rows == [([0, 1], [100, 101]), ([], []), ([8, 9, 10], [108, 109, 110])]
+    rows2, flag2 = HipEngine.collect(ids, frames, ext[:3])       # three bare tensors: same rows, flag unknown -> False
+    assert rows2 == rows and flag2 is False
+    d5 = Decoded(ids, frames, ext[:3], ext=ext, dump=torch.zeros(3, 2, 5), dump_count=torch.zeros(3, dtype=torch.int32))
+    assert len(d5) == 5 and d5[:3][0] is ids
+    # the decoding classes take the object whole
+    from gigaam_amd.decoding import CTCGreedyDecoding, RangeOverflow
+    d = CTCGreedyDecoding([chr(ord("a") + i) for i in range(12)])
+    with pytest.raises(RangeOverflow):
+        d.finish(dec)
+    clean = Decoded(ids, frames, ext[:3], ext=torch.tensor([2, 0, 3, 0], dtype=torch.int32))
+    assert [t for t, _, _ in d.finish(clean)] == ["ab", "", "ijk"]
+
+
+def test_side_cluster_sizes():
+    from gigaam_amd.engine import HipEngine
+    assert [HipEngine.side_cluster(b, 96) for b in (1, 8, 9, 16, 32, 33, 64, 200)] == [8, 8, 6, 6, 3, 2, 1, 1]
+    assert HipEngine.side_cluster(32, 160) == 5 and HipEngine.side_cluster(32, 32) == 1 and HipEngine.side_cluster(33, 8) == 1

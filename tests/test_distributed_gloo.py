@@ -78,6 +78,12 @@ def _worker(rank, world, port, q):
     res4b = shard.run_sharded(batches, lambda w, l: (order.append("launch"), (w, l))[1], rank, world, shard.torch_gather, cap=16,
                               collect=lambda h: (order.append("collect"), fake_decode(*h))[1])
     assert res4b == res4 and order[:3] == ["launch", "launch", "collect"][: len(order)]
+    # r05: with overlap_kw the launcher is told whether ANOTHER batch of this rank follows (an RNN-T decode then runs beside
+    # the next batch's encoder): True for every batch but the rank's last one, and the results do not change
+    flags = []
+    res4c = shard.run_sharded(batches, lambda w, l, overlap=False: (flags.append(overlap), (w, l))[1], rank, world, shard.torch_gather,
+                              cap=16, collect=lambda h: fake_decode(*h), overlap_kw=True)
+    assert res4c == res4 and flags == [True] * (len(flags) - 1) + [False] and len(flags) == len(shard.deal(len(batches), rank, world))
     # (c) config-5 style: chunks dealt by duration (LPT), each rank's share in length-sorted batches of 16, rows packed with
     #     their global (file-order) index
     segs = [torch.randn(30 + 7 * ((i * 11) % 41)) for i in range(41)]
