@@ -9,8 +9,9 @@ arbitrary length order, all model families (v1 rel-pos, v2, v3; CTC V = 34 / 257
 
 Bars: encoder activations <= TOL_ENC on valid frames; CTC log-probs <= 1e-3; ids + frames BIT-EXACT for every utterance
 whose smallest reference top-1 / top-2 margin exceeds 5e-4 (a random-weight head has near-ties; such an utterance is
-reported and must still agree up to the tied frames), and the test fails if fewer than 3/4 of the utterances were checked
-exactly.  Features come from the oracle's log-mel for the encoder comparison (row a1 is carved out: no torchaudio here) and
+reported and must still agree up to the tied frames), and the test fails if fewer than 3/4 (16-layer batches: 1/2) of the
+utterances were checked exactly; CTC heads are also compared per FRAME: wherever the reference's margin exceeds 5e-4 the HIP
+head picks the same class, on the reference's encoder output and through the whole path.  Features come from the oracle's log-mel for the encoder comparison (row a1 is carved out: no torchaudio here) and
 from the HIP frontend for the whole-path comparison.  Measured errors go to $GAM_TEST_REPORT.
 """
 import difflib
@@ -117,7 +118,7 @@ def _compare_decodes(tag, got, want, margins, min_exact_frac=0.75):
     return exact, near
 
 
-def _live_check(name, ck, wav, wlen, eng=None, probe=None):
+def _live_check(name, ck, wav, wlen, eng=None, min_exact_frac=0.75):
     """Run the reference on the host and the HIP path on the GPU over the same audio; assert the bars; return measurements."""
     cfg = ck["cfg"]
     is_rnnt = "RNNT" in cfg["decoding"]["_target_"]
@@ -143,13 +144,23 @@ def _live_check(name, ck, wav, wlen, eng=None, probe=None):
         lp = eng.ctc_head(enc_r).cpu()
         e_lp = float(((lp - lp_r) * vm[:, :, None]).abs().max())
         assert e_lp < TOL_LOGP, (name, e_lp)
-    n_alone, near_alone = _compare_decodes(name + ":decoder-alone", got_alone, want, margins)
+        # per FRAME (stronger than the per-utterance filter below, and never vacuous): wherever the reference's top-1 / top-2
+        # margin exceeds the near-tie bar, the HIP head picks the same class
+        t2 = lp_r.topk(2, dim=-1).values
+        sure = ((t2[..., 0] - t2[..., 1]) > NEAR_TIE) & vm
+        assert int(sure.sum()) >= 0.9 * int(vm.sum()), (name, "most frames are near-ties?", int(sure.sum()), int(vm.sum()))
+        assert bool((lp.argmax(-1) == lp_r.argmax(-1))[sure].all()), (name, "argmax differs on a frame with margin > 5e-4")
+    n_alone, near_alone = _compare_decodes(name + ":decoder-alone", got_alone, want, margins, min_exact_frac)
     # (3) whole path wav -> ids through the HIP frontend
     enc2, elen2 = eng.encode(*eng.frontend(wav, wlen))
     assert elen2.cpu().tolist() == elen_r.tolist()
     e_enc2 = float(((enc2.cpu() - enc_r) * vm[:, None, :]).abs().max())
     got = ragged_from_device(*(eng.rnnt_greedy(enc2, elen2, ms)[:3] if is_rnnt else eng.ctc_greedy(enc2, elen2)))
-    n_whole, near_whole = _compare_decodes(name + ":whole-path", got, want, margins)
+    if not is_rnnt:
+        am2 = eng.ctc_head(enc2).argmax(-1).cpu()      # (the HIP frontend's log-mel differs from the oracle's by up to 1.5e-4: a wider bar)
+        sure2 = ((t2[..., 0] - t2[..., 1]) > 4 * NEAR_TIE) & vm
+        assert bool((am2 == lp_r.argmax(-1))[sure2].all()), (name, "whole path: argmax differs on a frame with margin > 2e-3")
+    n_whole, near_whole = _compare_decodes(name + ":whole-path", got, want, margins, min_exact_frac)
     out = dict(case=name, utterances=len(want), enc_err=e_enc, enc_err_whole_path=e_enc2, tol=TOL_ENC,
                exact_decoder_alone=n_alone, exact_whole_path=n_whole, near_tie_utterances=near_whole,
                min_margin=float(min(margins)), tokens=sum(len(w[0]) for w in want))
@@ -185,7 +196,10 @@ def _ragged_fullsize(name, model, bias, wav, wlen):
     from gigaam_amd import synth
     ck = synth.make_checkpoint(model, seed=0, rnnt_blank_bias=bias)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    return _live_check(name, ck, wav, wlen)
+    # a random-weight 16-layer CTC head has a frame closer to a tie than 5e-4 in a good third of its 20 s utterances
+    # (tests/golden/fullsize32: margins 2.3e-5 .. 5.8e-3): those utterances fall under the edit-distance rule, every FRAME
+    # above the bar is still checked exactly, and half of the utterances must be exact end to end
+    return _live_check(name, ck, wav, wlen, min_exact_frac=0.5)
 
 
 def _blank_bias(model):
