@@ -21,7 +21,7 @@ def main():
     cfg = synth.model_cfg("v2_ctc")
     eng = HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], None), {}, torch.device("cuda:0"))
     eng.set_gemm_mode("f16x3")
-    m, n, k = 16064, 3072, 3072
+    m, n, k = (int(x) for x in sys.argv[1:4]) if len(sys.argv) >= 4 else (16064, 3072, 3072)
     out = []
     for name in ("zeros", "randn", "zeros", "randn"):
         a = torch.zeros(m, k, device="cuda") if name == "zeros" else torch.randn(m, k, device="cuda")
@@ -42,7 +42,7 @@ def main():
                "algorithmic_tflops": round(2.0 * m * n * k * reps / dt / 1e12, 1), **ps.summary()}
         out.append(rec)
         print(json.dumps(rec), flush=True)
-    path = os.path.join(ROOT, "gpurun_out", "power_gemm.jsonl")
+    path = os.path.join(ROOT, "gpurun_out", f"power_gemm_{m}x{n}x{k}.jsonl")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
         for r in out:
