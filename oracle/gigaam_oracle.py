@@ -14,7 +14,8 @@ Pinning status
   on identical seeded weights/inputs in the build container, asserts agreement
   (<=2e-5 abs on encoder outputs, exact ids/frames), and commits the reference's
   outputs as fixtures under tests/golden/ which tests/test_oracle_golden.py
-  re-checks on every run (the reference tree does not travel to the GPU box).
+  re-checks on every run.  (r05: the reference itself travels too, as bytecode -- oracle/build_ref.py, oracle/ref_shim.py --
+  and runs beside the kernels in tests/test_hip_vs_reference_live.py and bench.py's cpu_baseline leg.)
 * a1 (FeatureExtractor = torchaudio.transforms.MelSpectrogram + log): PARITY
   UNPINNED.  torchaudio (pinned only as ``torchaudio>=2.6`` in the reference's
   pyproject.toml:30-33) is not installed and not under /root/reference, and
