@@ -54,6 +54,41 @@ def run(name, fn, spin_us=3000.0, lds_kb=LDS_KB):
           + (f", byte offsets {lo} .. {hi}, samples {samples[:2]}" if tot_wg else ""), flush=True)
 
 
+def run_late(name, fn, lds_kb=LDS_KB, n_canaries=12, spin_us=150.0):
+    """The canaries START while the other stream's kernels are already running: their workgroups are placed on LDS that a retiring
+    workgroup of the other kernel has just freed -- a write of that kernel still in flight at its retirement would land in the canary."""
+    tot_changed = tot_wg = 0
+    samples = []
+    for _ in range(REPS):
+        outs = [torch.zeros((N_WG, OUT_WORDS), dtype=torch.int32, device="cuda") for _ in range(n_canaries)]
+        torch.cuda.synchronize()
+        fn()
+        with torch.cuda.stream(side):
+            for out in outs:
+                rc = lib.lds_canary_launch(C.c_void_p(out.data_ptr()), N_WG, lds_kb * 1024, spin_us, C.c_void_p(side.cuda_stream))
+                assert rc == 0, rc
+        fn()
+        torch.cuda.synchronize()
+        for out in outs:
+            o = out.cpu().numpy().view("uint32")
+            hit = o[:, 0] > 0
+            tot_changed += int(o[:, 0].sum()); tot_wg += int(hit.sum())
+            for r in o[hit][:1]:
+                samples.append([(int(r[4 + k]), hex(int(r[10 + k]))) for k in range(int(r[3]))])
+    print(f"LATE  {name:38s} canary LDS {lds_kb:3d} KB: workgroups hit {tot_wg:5d} of {REPS * N_WG * n_canaries}, words changed {tot_changed:7d}"
+          + (f", samples {samples[:3]}" if tot_wg else ""), flush=True)
+
+
+if os.environ.get("LATE"):
+    run_late("op_gemm 640 x 768 x 768", lambda: [eng.op_gemm(x640, w768) for _ in range(40)])
+    run_late("op_gemm 640 x 768 x 768", lambda: [eng.op_gemm(x640, w768) for _ in range(40)], lds_kb=100)
+    run_late("op_gemm 2008 x 3072 x 768", lambda: [eng.op_gemm(x2008, w3072) for _ in range(20)])
+    run_late("op_gemm 16064 x 768 x 768", lambda: [eng.op_gemm(x16k, w768) for _ in range(4)], lds_kb=120)
+    for st in (2, 3):
+        eng.lib.gam_tune_sp_stages(st)
+        run_late(f"op_gemm 640, stages {st}", lambda: [eng.op_gemm(x640, w768) for _ in range(40)])
+    eng.lib.gam_tune_sp_stages(0)
+    sys.exit(0)
 run("nothing beside it", lambda: None)
 run("op_gemm 640 x 768 x 768 (small tiles, split-K)", lambda: [eng.op_gemm(x640, w768) for _ in range(40)])
 run("op_gemm 2008 x 3072 x 768", lambda: [eng.op_gemm(x2008, w3072) for _ in range(20)])
