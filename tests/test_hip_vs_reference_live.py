@@ -5,7 +5,8 @@ The committed fixtures replay 18 fixed cases; here the reference's unmodified ``
 ``oracle/build_ref.py``; the source tree itself in the build container) run on the host CPU on shapes NO fixture holds --
 tile-edge encoder lengths T' in {1, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257}, batches of 1 / 2 / 5 / 33 in
 arbitrary length order, all model families (v1 rel-pos, v2, v3; CTC V = 34 / 257; RNN-T V = 34 / 1025) -- and on one ragged
-16-layer batch each of BASELINE configs 2 / 3 (``linspace(10 s, 20 s, 32)``) and 4 (32 x U(5, 20) s, V = 1025).
+16-layer batch each of BASELINE configs 2 / 3 (``linspace(10 s, 20 s, 32)``), 4 (32 x U(5, 20) s, V = 1025) and 5 (the 16
+longest chunks of the hour-long file).
 
 Bars: encoder activations <= TOL_ENC on valid frames; CTC log-probs <= 1e-3; ids + frames BIT-EXACT for every utterance
 whose smallest reference top-1 / top-2 margin exceeds 5e-4 (a random-weight head has near-ties; such an utterance is
@@ -231,6 +232,18 @@ def test_fullsize_ragged_config4_against_live_reference():
     wav, wlen, _ = workloads.config4_batches(n_utts=1024, batch=32, only_batches=[16])[0]
     out = _ragged_fullsize("fullsize/config4_batch16", "v3_e2e_rnnt", _blank_bias("v3_e2e_rnnt"), wav, wlen)
     assert out["utterances"] == 32
+
+
+def test_fullsize_ragged_config5_batch_against_live_reference():
+    """BASELINE config 5: v2_ctc, 16 layers, one REAL batch of the hour-long file -- the 16 chunks rank 0 decodes first (the longest of
+    the 194 the reference's packer cuts, collated exactly as the feeder does); the committed fixture holds 3 chunks."""
+    from gigaam_amd import shard, workloads
+    from gigaam_amd.feeder import collate
+    segs, _ = workloads.config5_segments(3600)
+    rows = shard.rank_batches([int(x.shape[0]) for x in segs], 1, 16)[0][0]
+    wav, wlen = collate([segs[i] for i in rows])
+    out = _ragged_fullsize("fullsize/config5_batch0", "v2_ctc", None, wav, wlen)
+    assert out["utterances"] == 16
 
 
 def test_onnx_twin_decoders_agree_with_the_hip_decoders():
