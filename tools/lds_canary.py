@@ -79,6 +79,39 @@ def run_late(name, fn, lds_kb=LDS_KB, n_canaries=12, spin_us=150.0):
           + (f", samples {samples[:3]}" if tot_wg else ""), flush=True)
 
 
+if os.environ.get("LOADS"):
+    # canary 2: VGPR-returning global loads of a workgroup that shares its CU with the GEMM's workgroups
+    lib.load_canary_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    n_words = 4 << 20                                  # 16 MB: L2-resident or not, both
+    buf = torch.empty((n_words,), dtype=torch.int32, device="cuda")
+    assert lib.load_canary_launch(None, C.c_void_p(buf.data_ptr()), n_words, 1, 0, 0, 0.0, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    torch.cuda.synchronize()
+
+    def run_loads(name, fn, lds_kb=56, spin_us=3000.0):
+        bad_wg = bad = passes = 0
+        first = None
+        for _ in range(REPS):
+            out = torch.zeros((N_WG, 8), dtype=torch.int32, device="cuda")
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                rc = lib.load_canary_launch(C.c_void_p(out.data_ptr()), C.c_void_p(buf.data_ptr()), n_words, 0, N_WG, lds_kb * 1024, spin_us, C.c_void_p(side.cuda_stream))
+                assert rc == 0, rc
+            fn()
+            torch.cuda.synchronize()
+            o = out.cpu().numpy().view("uint32")
+            bad_wg += int((o[:, 0] > 0).sum()); bad += int(o[:, 0].sum()); passes += int(o[:, 4].sum())
+            if first is None and (o[:, 0] > 0).any():
+                r = o[o[:, 0] > 0][0]
+                first = (int(r[1]), hex(int(r[2])), hex(int(r[3])))
+        print(f"LOADS {name:44s} LDS {lds_kb:3d} KB: workgroups with a wrong word {bad_wg:5d} of {REPS * N_WG}, wrong words {bad}, 16 x 16-byte load batches checked {passes * 256}"
+              + (f", first (word, got, want) {first}" if first else ""), flush=True)
+
+    run_loads("nothing beside it", lambda: None)
+    run_loads("op_gemm 640 x 768 x 768 (small tiles, split-K)", lambda: [eng.op_gemm(x640, w768) for _ in range(60)])
+    run_loads("op_gemm 2008 x 3072 x 768", lambda: [eng.op_gemm(x2008, w3072) for _ in range(30)])
+    run_loads("op_gemm 640 x 768 x 768, canary LDS 24 KB", lambda: [eng.op_gemm(x640, w768) for _ in range(60)], lds_kb=24)
+    run_loads("op_attention 5 x 120", lambda: [eng.op_attention(q, q, q, ql) for _ in range(60)])
+    sys.exit(0)
 if os.environ.get("LATE"):
     run_late("op_gemm 640 x 768 x 768", lambda: [eng.op_gemm(x640, w768) for _ in range(40)])
     run_late("op_gemm 640 x 768 x 768", lambda: [eng.op_gemm(x640, w768) for _ in range(40)], lds_kb=100)

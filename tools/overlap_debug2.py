@@ -18,6 +18,11 @@ for k in range(6):
     batches.append((w.cuda(), l.cuda()))
 xa_small = torch.randn(640, 768, device="cuda"); xa_big = torch.randn(16064, 768, device="cuda"); wa = torch.randn(768, 768, device="cuda") * 0.03
 qa = torch.randn(5, 120, 768, device="cuda"); la = torch.tensor([120, 100, 90, 77, 50], device="cuda")
+canary = None
+if os.environ.get("BESIDE", "").startswith("canary"):
+    import ctypes as C
+    canary = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblds_canary.so"))
+    canary.lds_canary_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
 eng2 = None
 if os.environ.get("BESIDE") == "other_handle":
     model2 = gigaam_amd.model_from_checkpoint(ck, "cuda:0")
@@ -48,6 +53,12 @@ for rep in range(REPS):
                 eng.frontend(w2, l2)
             elif os.environ.get("BESIDE") == "big_encoder":
                 eng.encode(*eng.frontend(*batches[1]))
+            elif os.environ.get("BESIDE", "").startswith("canary"):
+                # a neighbour that only holds LDS and re-reads it (tools/lds_canary.hip): does ANY co-resident workgroup perturb the decode?
+                import ctypes as C
+                kb = int(os.environ["BESIDE"].split(":")[1]) if ":" in os.environ["BESIDE"] else 90
+                out_c = torch.zeros((256, 18), dtype=torch.int32, device="cuda")
+                canary.lds_canary_launch(C.c_void_p(out_c.data_ptr()), 256, kb * 1024, 4000.0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
             elif os.environ.get("BESIDE") == "op_gemm_small":
                 for _ in range(40): eng.op_gemm(xa_small, wa)
             elif os.environ.get("BESIDE") == "op_gemm_big":
