@@ -19,6 +19,7 @@ for k in range(6):
 xa_small = torch.randn(640, 768, device="cuda"); xa_big = torch.randn(16064, 768, device="cuda"); wa = torch.randn(768, 768, device="cuda") * 0.03
 qa = torch.randn(5, 120, 768, device="cuda"); la = torch.tensor([120, 100, 90, 77, 50], device="cuda")
 canary = None
+sq_stream = None
 if os.environ.get("BESIDE", "").startswith("canary"):
     import ctypes as C
     canary = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblds_canary.so"))
@@ -43,6 +44,19 @@ for rep in range(REPS):
     if os.environ.get("ONLY_B"):
         pend, got = None, []
         for k, (enc, elen) in enumerate(encs):
+            if os.environ.get("BESIDE") == "squeeze":
+                # spinner workgroups holding the WHOLE LDS of most CUs for 25 ms, launched first: the decode's workgroups must pack two per CU
+                # onto the few CUs left (its C <= 4 variants have an occupancy of two) with NOTHING else running
+                import ctypes as C
+                if canary is None:
+                    canary = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblds_canary.so"))
+                    canary.lds_canary_launch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
+                out_c = torch.zeros((256, 18), dtype=torch.int32, device="cuda")
+                if sq_stream is None:
+                    sq_stream = torch.cuda.Stream()
+                sq_stream.wait_stream(torch.cuda.current_stream())
+                canary.lds_canary_launch(C.c_void_p(out_c.data_ptr()), int(os.environ.get("SQUEEZE_WGS", "200")), 159 * 1024, 25000.0,
+                                         C.c_void_p(sq_stream.cuda_stream))
             dec = eng.rnnt_greedy(enc, elen, ms, overlap=True, side_cus=int(os.environ.get("SIDE_CUS", "64")))
             w2, l2 = batches[(k + 1) % 6]
             if os.environ.get("BESIDE") == "matmul":
@@ -59,6 +73,8 @@ for rep in range(REPS):
                 kb = int(os.environ["BESIDE"].split(":")[1]) if ":" in os.environ["BESIDE"] else 90
                 out_c = torch.zeros((256, 18), dtype=torch.int32, device="cuda")
                 canary.lds_canary_launch(C.c_void_p(out_c.data_ptr()), 256, kb * 1024, 4000.0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            elif os.environ.get("BESIDE") == "squeeze":
+                pass      # (the spinner was launched BEFORE the decode: see below)
             elif os.environ.get("BESIDE") == "op_gemm_small":
                 for _ in range(40): eng.op_gemm(xa_small, wa)
             elif os.environ.get("BESIDE") == "op_gemm_big":
