@@ -147,6 +147,11 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
   unsigned long long* xp = xh + 2 * H;                                                  // [2][JH]
   unsigned long long* xa = xp + 2 * JH;                                                 // [2][C][WIN][3]
 
+#if defined(GAM_RC_FULLREGS) && GAM_RC_FULLREGS
+  // r05 diagnosis build only (-DGAM_RC_FULLREGS=1): touching the last accumulation register makes the wave's allocation the whole
+  // 512-entry register file of its SIMD, so no other wave can be placed beside it on that SIMD (the LDS / CU can still be shared)
+  asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
+#endif
   for (int i = tid; i < H; i += 256) { h_s[i] = 0.f; c_s[i] = 0.f; }
   if (tid == 0) dead_s[0] = 0;
   if (wout_l != nullptr)
