@@ -61,20 +61,34 @@ enum { T_GATES = 1, T_XH, T_PRED, T_XP, T_Z, T_JOINT, T_XA, T_COMB, T_CTRL, T_RO
 // "every load issued so far has landed", as a compiler barrier too: keeps a batch of independent loads TOGETHER in front of
 // their uses (hipcc otherwise sinks each load into the conditional block that consumes it: one L2 round trip per load)
 #define GAM_RC_LOADS_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// r05 diagnosis (GAM_RNNT_DBG bit 512 / per-site bits 1 << (12 + site)): drain every counter and barrier at a named point of the round
+#define GAM_RC_PARANOID(site)                                                          \
+  if ((g.dbg & 512) || (g.dbg & (1 << (12 + (site))))) {                              \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                        \
+    __syncthreads();                                                                   \
+  }
 
-__device__ __forceinline__ void gam_rc_put(unsigned long long* p, float v, unsigned tag) {
-  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
+// (sys: r05 diagnosis switch, GAM_RNNT_DBG bit 128 -- the hand-off at system scope with release / acquire ordering)
+__device__ __forceinline__ void gam_rc_put(unsigned long long* p, float v, unsigned tag, const bool sys = false) {
+  const unsigned long long w = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+  if (sys) __hip_atomic_store(p, w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  else __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // poll granule p0 and (when ``two``) p1 until their tags match, both loads in flight: one L2 round trip instead of two
 // for the threads that own two granules of a 320-wide exchange; false on timeout / launch-wide abort
 __device__ __forceinline__ bool gam_rc_get2(const unsigned long long* p0, const unsigned long long* p1, bool two, unsigned tag,
-                                            float& v0, float& v1, int* status) {
+                                            float& v0, float& v1, int* status, const bool sys = false) {
   long long t_end = 0;
   bool d0 = false, d1 = !two;
   for (unsigned spin = 0;; ++spin) {
-    const unsigned long long g0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long g1 = __hip_atomic_load(two ? p1 : p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long g0, g1;
+    if (sys) {
+      g0 = __hip_atomic_load(p0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+      g1 = __hip_atomic_load(two ? p1 : p0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      g0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      g1 = __hip_atomic_load(two ? p1 : p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (!d0 && (unsigned)(g0 >> 32) == tag) { v0 = __uint_as_float((unsigned)g0); d0 = true; }
     if (!d1 && (unsigned)(g1 >> 32) == tag) { v1 = __uint_as_float((unsigned)g1); d1 = true; }
     if (d0 && d1) return true;
@@ -211,6 +225,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
   unsigned xc = 0;     // exchange counter = tag
   int par_h = 0, par_p = 0, par_a = 0;
   bool dead = g.force_dead && (b & 1);
+  const bool sysx = (g.dbg & 128) != 0;
 
 #if GAM_RC_TIMING
   long long tacc[12] = {0}, tlast = wall_clock64();
@@ -268,6 +283,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       }
       __syncthreads();
     GAM_RC_MARK(T_GATES);
+    GAM_RC_PARANOID(0);
       ++xc;
       for (int ii = tid; i0 + ii < i1; ii += 256) {   // cell update of my units (gate order i, f, g, o)
         const float ig = gam_sigmoid_exact(gates[ii]), fg = gam_sigmoid_exact(gates[nI + ii]);
@@ -275,14 +291,14 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
         const float cn = fg * c_s[ii] + ig * gg;
         const float hn = og * tanhf(cn);
         cn_s[ii] = cn;
-        if (C > 1) gam_rc_put(xh + par_h * H + i0 + ii, hn, xc);
+        if (C > 1) gam_rc_put(xh + par_h * H + i0 + ii, hn, xc, sysx);
         else hn_s[i0 + ii] = hn;
       }
       if (C > 1) {
         for (int i = tid; i < H; i += 512) {
           float va = 0.f, vb = 0.f;
           const bool two = i + 256 < H;
-          if (!gam_rc_get2(xh + par_h * H + i, xh + par_h * H + i + 256, two, xc, va, vb, g.status)) { dead_s[0] = 1; va = vb = 0.f; }
+          if (!gam_rc_get2(xh + par_h * H + i, xh + par_h * H + i + 256, two, xc, va, vb, g.status, sysx)) { dead_s[0] = 1; va = vb = 0.f; }
           hn_s[i] = va;
           if (two) hn_s[i + 256] = vb;
         }
@@ -290,6 +306,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       }
       __syncthreads();
     GAM_RC_MARK(T_XH);
+    GAM_RC_PARANOID(1);
       if (dead_s[0]) { dead = true; break; }
       // ---- my rows of W_pred.h' + b_pred
       {
@@ -341,18 +358,19 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       }
       __syncthreads();
     GAM_RC_MARK(T_PRED);
+    GAM_RC_PARANOID(2);
       ++xc;
       for (int rr = tid; r0 + rr < r1; rr += 256) {
         float v = red[rr];
         for (int p = 1; p < P; ++p) v += red[p * nP + rr];
-        if (C > 1) gam_rc_put(xp + par_p * JH + r0 + rr, v, xc);
+        if (C > 1) gam_rc_put(xp + par_p * JH + r0 + rr, v, xc, sysx);
         else pp[r0 + rr] = v;
       }
       if (C > 1) {
         for (int i = tid; i < JH; i += 512) {
           float va = 0.f, vb = 0.f;
           const bool two = i + 256 < JH;
-          if (!gam_rc_get2(xp + par_p * JH + i, xp + par_p * JH + i + 256, two, xc, va, vb, g.status)) { dead_s[0] = 1; va = vb = 0.f; }
+          if (!gam_rc_get2(xp + par_p * JH + i, xp + par_p * JH + i + 256, two, xc, va, vb, g.status, sysx)) { dead_s[0] = 1; va = vb = 0.f; }
           pp[i] = va;
           if (two) pp[i + 256] = vb;
         }
@@ -361,6 +379,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       need_pred = false;
       __syncthreads();
     GAM_RC_MARK(T_XP);
+    GAM_RC_PARANOID(3);
       if (dead_s[0]) { dead = true; break; }
     }
 
@@ -378,6 +397,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
     }
     __syncthreads();
     GAM_RC_MARK(T_Z);
+    GAM_RC_PARANOID(4);
     // logits[f][v] = bout[v] + sum_k z[f][k] wout[v][k] for my classes: one 16x16 MFMA tile per 16 classes
     for (int nt = wave; v0 + nt * 16 < v1; nt += 4) {
       const int v = v0 + nt * 16 + li;
@@ -421,6 +441,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
     }
     __syncthreads();
     GAM_RC_MARK(T_JOINT);
+    GAM_RC_PARANOID(5);
     // per-frame (max, first argmax, sum-exp) over my classes: 16 lanes per frame, wave w takes frames 4w .. 4w+3
     ++xc;
     const int NG = a.dump != nullptr ? 3 : 2;   // (the sum-exp is only exchanged when log-probs are dumped)
@@ -450,9 +471,9 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       if (li == 0) {
         if (C > 1) {
           unsigned long long* q = xa + (((size_t)par_a * C + cm) * GAM_RC_WIN + f) * 3;
-          gam_rc_put(q + 0, best, xc);
-          gam_rc_put(q + 1, __int_as_float(bi), xc);
-          if (NG == 3) gam_rc_put(q + 2, se, xc);
+          gam_rc_put(q + 0, best, xc, sysx);
+          gam_rc_put(q + 1, __int_as_float(bi), xc, sysx);
+          if (NG == 3) gam_rc_put(q + 2, se, xc, sysx);
         } else {
           apart[f * 3 + 0] = best; apart[f * 3 + 1] = __int_as_float(bi); apart[f * 3 + 2] = se;
         }
@@ -465,7 +486,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
         const bool two = i + 256 < n;
         const int ia = i / NG * 3 + i % NG, ib = (i + 256) / NG * 3 + (i + 256) % NG;
         const unsigned long long* base = xa + (size_t)par_a * C * GAM_RC_WIN * 3;
-        if (!gam_rc_get2(base + ia, base + ib, two, xc, va, vb, g.status)) { dead_s[0] = 1; va = vb = 0.f; }
+        if (!gam_rc_get2(base + ia, base + ib, two, xc, va, vb, g.status, sysx)) { dead_s[0] = 1; va = vb = 0.f; }
         apart[ia] = va;
         if (two) apart[ib] = vb;
       }
@@ -473,6 +494,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
     }
     __syncthreads();
     GAM_RC_MARK(T_XA);
+    GAM_RC_PARANOID(6);
     if (dead_s[0]) { dead = true; break; }
     // combine the members' slices (ascending class order: the first maximum wins).  Every wave does it for all 16
     // frames (lane & 15 = frame), so the window's verdict needs no further barrier: a ballot gives the first
@@ -501,6 +523,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       }
     }
     GAM_RC_MARK(T_COMB);
+    GAM_RC_PARANOID(7);
     const int n_eval = fstar < W ? fstar + 1 : W;   // joint evaluations the sequential loop performs
     if (a.dump != nullptr) {
       for (int f = 0; f < n_eval; ++f) {
@@ -540,9 +563,11 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       if (sym >= a.max_symbols) { t = te + 1; sym = 0; }   // frame advances regardless (decoding.py:189-205)
       else t = te;
     }
+    GAM_RC_PARANOID(9);
     if (t < len) fetch_window(t);
     __syncthreads();
     GAM_RC_MARK(T_CTRL);
+    GAM_RC_PARANOID(8);
   }
 #if GAM_RC_TIMING
   if (b == 0 && cm == 0 && tid == 0)
