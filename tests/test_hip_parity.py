@@ -724,6 +724,39 @@ def test_longform_consistency(tmp_path):
         assert (a.start, a.end) == (b.start, b.end) and a.text == b.text
 
 
+def test_longform_rnnt_overlapped_pipeline_matches_per_batch_decodes(tmp_path):
+    """r05: transcribe_longform of an RNN-T model runs the greedy decode of batch n on the side stream beside the encoder of batch n + 1
+    (model.launch_batch(overlap=True) for every batch but the last).  Five batches of a 60 s file: the segments' texts must equal what the
+    same chunks give decoded batch by batch with the decode in front (transcribe_batch), and two runs must agree."""
+    import wave
+    import gigaam_amd
+    from gigaam_amd import synth
+    from gigaam_amd.feeder import batches, collate
+    from gigaam_amd.vad_utils import pack_regions
+    ck = synth.make_checkpoint("v2_rnnt", seed=1, n_layers=2, rnnt_blank_bias=13.5)
+    model = gigaam_amd.model_from_checkpoint(ck, "cuda:0")
+    wav, _ = synth.synth_audio(1, 60.0, seed=21)
+    pcm = (wav[0].numpy() * 32768.0).round().clip(-32768, 32767).astype(np.int16)
+    wpath = str(tmp_path / "long_rnnt.wav")
+    with wave.open(wpath, "wb") as wf:
+        wf.setnchannels(1); wf.setsampwidth(2); wf.setframerate(16000); wf.writeframes(pcm.tobytes())
+    regions = [(0.2 + 4.0 * i, 3.9 + 4.0 * i) for i in range(14)]
+    kw = dict(speech_regions=regions, min_duration=1.0, max_duration=4.5, fr_batch_size=3)
+    r1 = model.transcribe_longform(wpath, **kw)
+    r2 = model.transcribe_longform(wpath, **kw)
+    assert len(r1.segments) >= 12 and [s.text for s in r1.segments] == [s.text for s in r2.segments]
+    audio = torch.from_numpy(pcm.astype(np.float32) / 32768.0)
+    bounds = pack_regions(regions, audio.shape[0] / 16000.0, min_duration=1.0, max_duration=4.5)
+    assert [(s.start, s.end) for s in r1.segments] == [tuple(b) for b in bounds]
+    chunks = [audio[int(s * 16000): int(e * 16000)] for s, e in bounds]
+    want = []
+    for c in batches(chunks, 3):
+        want += [t for t, _ in model.transcribe_batch(*collate(c))]
+    got = [s.text for s in r1.segments]
+    # (the overlapped decodes use smaller clusters than the serial ones: a logit may move by 1e-6, which only a near-tie shows)
+    assert sum(a == b for a, b in zip(got, want)) >= len(want) - 1 and sum(len(t) for t in want) > 20, (got, want)
+
+
 @pytest.mark.parametrize("revision", ["v3_ctc", "v3_e2e_ctc"])
 def test_transcribe_result_structure_v3(revision, tmp_path):
     """reference tests/test_timestamps.py:112-215 on synthetic checkpoints: the structure and ordering invariants of
