@@ -56,6 +56,7 @@ SIGNATURES = {
     "gam_set_gemm_mode": (C.c_int, [_P, C.c_int]),
     "gam_get_gemm_mode": (C.c_int, [_P]),
     "gam_set_rnnt_cluster": (C.c_int, [_P, C.c_int]),
+    "gam_get_rnnt_cluster": (C.c_int, [_P]),
     "gam_debug_buffer_hash": (C.c_int, [_P, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int64)]),
     "gam_range_flag": (C.c_int, [_P, C.POINTER(C.c_int), _P]),
     "gam_range_flag_fetch": (C.c_int, [_P, _P, _P]),

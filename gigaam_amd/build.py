@@ -1,28 +1,96 @@
-"""Build libgigaam_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build libgigaam_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU), then gate its device code.
+
+The gate (r06): on MI355X a ``v_pk_{fma,mul,add}_f32`` whose ``op_sel`` selects the HIGH register of its src1 pair for the low result
+returns a wrong low result in lanes 48..63 whenever another wave on the same SIMD issues MFMAs -- of another stream's kernel or of the
+same workgroup (tools/pkfma_rule.hip, profiles/r06_pkfma_rule.txt; alone on the SIMD it never fails).  hipcc's SLP vectorizer
+produces exactly that form when it packs two scalar FMA chains that share a broadcast operand (the RNN-T decode's gate rows: the r05
+"co-residency perturbation").  The library is therefore compiled with ``-fno-slp-vectorize`` and the build FAILS if the code object
+still holds such an instruction (explicit two-float vector code could bring one back).
+"""
 from __future__ import annotations
 
 import os
+import re
 import shutil
+import struct
 import subprocess
+import tempfile
+from typing import List
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "libgigaam_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-fno-slp-vectorize"]
+# low result <- src1 HIGH: the second op_sel bit of a packed-fp32 VOP3P instruction
+_RISKY = re.compile(r"\bv_pk_(?:fma|mul|add)_f32\b[^\n]*\bop_sel:\[[01],1[,\]]")
+_OBJDUMP_DIRS = ["/opt/rocm/lib/llvm/bin", "/opt/rocm/llvm/bin"]
 
 
 def _newest_src() -> float:
     inc = os.path.join(os.path.dirname(_HERE), "include", "gigaam_hip.h")
-    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [inc]
+    files = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [inc, os.path.abspath(__file__)]
     return max(os.path.getmtime(f) for f in files)
+
+
+def device_code_objects(lib_path: str) -> List[bytes]:
+    """The gfx950 code objects inside a hipcc fat binary (clang offload bundle, uncompressed)."""
+    data = open(lib_path, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out, pos = [], 0
+    while True:
+        i = data.find(magic, pos)
+        if i < 0:
+            break
+        n = struct.unpack_from("<Q", data, i + 24)[0]
+        off = i + 32
+        for _ in range(n):
+            o, size, tlen = struct.unpack_from("<QQQ", data, off)
+            off += 24
+            triple = data[off:off + tlen].decode(errors="replace")
+            off += tlen
+            if "amdgcn" in triple and size > 0:
+                out.append(data[i + o:i + o + size])
+        pos = i + len(magic)
+    return out
+
+
+def risky_packed_f32(lib_path: str) -> List[str]:
+    """Disassemble the library's device code; return every packed-fp32 instruction of the erratum's form (empty = clean)."""
+    objdump = shutil.which("llvm-objdump") or next((os.path.join(d, "llvm-objdump") for d in _OBJDUMP_DIRS
+                                                    if os.path.exists(os.path.join(d, "llvm-objdump"))), None)
+    if objdump is None:
+        raise RuntimeError("llvm-objdump not found: cannot gate the device code (gigaam_amd/build.py)")
+    cos = device_code_objects(lib_path)
+    if not cos:
+        raise RuntimeError(f"no amdgcn code object found in {lib_path}")
+    hits: List[str] = []
+    for co in cos:
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            txt = subprocess.run([objdump, "-d", f.name], check=True, capture_output=True, text=True).stdout
+        kernel = "?"
+        for ln in txt.splitlines():
+            if ln.endswith(">:") and "<" in ln:
+                kernel = ln[ln.index("<") + 1:-2]
+            elif _RISKY.search(ln):
+                hits.append(f"{kernel}: {ln.split('//')[0].strip()}")
+    return hits
 
 
 def build_library(force: bool = False, verbose: bool = True) -> str:
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= _newest_src():
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-           os.path.join(CSRC, "gam_api.hip"), "-o", OUT]
+    tmp = OUT + ".tmp"
+    cmd = [hipcc] + FLAGS + [os.path.join(CSRC, "gam_api.hip"), "-o", tmp]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
+    hits = risky_packed_f32(tmp)
+    if hits:
+        os.unlink(tmp)
+        raise RuntimeError("device code holds packed-fp32 instructions whose low result reads the high half of src1 (unreliable beside MFMA "
+                           "waves on MI355X, see gigaam_amd/build.py):\n  " + "\n  ".join(hits[:20]))
+    os.replace(tmp, OUT)
     return OUT

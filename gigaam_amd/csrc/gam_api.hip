@@ -111,6 +111,15 @@ struct gam_handle {
   int rnnt_force_timeout = 0;   // GAM_RNNT_FORCE_TIMEOUT=1 (test hook): odd utterances' clusters report a failed hand-off
   int rnnt_exclusive = 1;       // GAM_RNNT_EXCLUSIVE=0: decode workgroups ask for their own LDS size only (default: the CU's whole LDS)
   DevBuf rnnt_x;                // hand-off granules + status word of the cluster kernel
+  DevBuf rnnt_audit;            // -DGAM_RC_AUDIT=1 diagnosis builds: the cluster kernel's audit log
+  bool audit_pending = false; int audit_last_c = 0; long audit_decodes = 0, audit_hit_decodes = 0;
+  // The decode class owns ONE set of scratch per handle (tok / logits / encp / rnnt_x / jz / jp / jl / dec_splitk_ws).  Every decode-class
+  // entry point records dec_evt behind its last launch; a decode-class call on ANOTHER stream waits for it first (DecodeScope), so two
+  // decodes of one handle are ordered whatever streams the caller puts them on (an overlapped decode on the side stream followed
+  // by a serial one on the launch stream overwrote the scratch the first was still reading).
+  hipEvent_t dec_evt = nullptr;
+  hipStream_t dec_stream = nullptr;
+  bool dec_evt_set = false;
 
   // workspace (grow-only)
   DevBuf wavp, spec, img, c2, xin, y1, x, y, yr, hbuf, qkv, ctx, ubuf, zbuf, tok, logits, encp, pbuf, aplanes;
@@ -461,6 +470,20 @@ int layernorm(gam_handle* h, hipStream_t s, GamLnArgs a, int mode, PendingReduce
 
 int64_t half_up(int64_t l) { return l <= 0 ? 0 : (l + 1) / 2; }
 
+// Orders a decode-class call behind the previous decode-class call of the handle when the two run on different streams, and records its
+// own completion for the next one (see gam_handle::dec_evt).  Same stream: no wait is enqueued, stream order does it.
+struct DecodeScope {
+  gam_handle* h;
+  hipStream_t s;
+  DecodeScope(gam_handle* h_, hipStream_t s_) : h(h_), s(s_) {
+    if (h->dec_evt == nullptr && hipEventCreateWithFlags(&h->dec_evt, hipEventDisableTiming) != hipSuccess) { h->dec_evt = nullptr; (void)hipGetLastError(); }
+    if (h->dec_evt != nullptr && h->dec_evt_set && h->dec_stream != s) (void)hipStreamWaitEvent(s, h->dec_evt, 0);
+  }
+  ~DecodeScope() {
+    if (h->dec_evt != nullptr && hipEventRecord(h->dec_evt, s) == hipSuccess) { h->dec_stream = s; h->dec_evt_set = true; }
+  }
+};
+
 }  // namespace
 
 // ===================================================================================
@@ -482,7 +505,7 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   if (const char* e = getenv("GAM_FUSE_REDUCE")) h->fuse_reduce = atoi(e);
   if (const char* e = getenv("GAM_GRAPH")) h->use_graph = atoi(e);
   if (const char* e = getenv("GAM_GRAPH_MAX_ROWS")) h->graph_max_rows = atoi(e);
-  if (const char* e = getenv("GAM_RNNT_CLUSTER")) h->rnnt_cluster = atoi(e);
+  if (const char* e = getenv("GAM_RNNT_CLUSTER")) h->rnnt_cluster = std::max(-1, std::min(8, atoi(e)));   // (the range gam_set_rnnt_cluster accepts)
   if (const char* e = getenv("GAM_RNNT_EXCLUSIVE")) h->rnnt_exclusive = atoi(e);
   if (const char* e = getenv("GAM_RNNT_COOP")) h->rnnt_coop = atoi(e);
   if (const char* e = getenv("GAM_RNNT_FORCE_TIMEOUT")) h->rnnt_force_timeout = atoi(e);
@@ -512,12 +535,19 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   return 0;
 }
 
+#if GAM_RC_AUDIT
+static int audit_dump(gam_handle* h);
+#endif
 void gam_destroy(gam_handle* h) {
   if (!h) return;
   hipSetDevice(h->device);
+#if GAM_RC_AUDIT
+  audit_dump(h);
+  fprintf(stderr, "[gam-audit] total: %ld of %ld cluster decodes logged at least one entry\n", h->audit_hit_decodes, h->audit_decodes);
+#endif
   for (void* p : h->owned) hipFree(p);
   DevBuf* bufs[] = {&h->wavp, &h->spec, &h->img, &h->c2, &h->xin, &h->y1, &h->x, &h->y, &h->yr, &h->hbuf,
-                    &h->qkv, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes, &h->op_sp, &h->splitk_ws, &h->dec_splitk_ws, &h->rsbuf, &h->op_rs, &h->rnnt_x, &h->jz, &h->jp, &h->jl};
+                    &h->qkv, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes, &h->op_sp, &h->splitk_ws, &h->dec_splitk_ws, &h->rsbuf, &h->op_rs, &h->rnnt_x, &h->rnnt_audit, &h->jz, &h->jp, &h->jl};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   if (h->lens) hipFree(h->lens);
@@ -526,6 +556,7 @@ void gam_destroy(gam_handle* h) {
   for (auto& g : h->graphs)
     if (g.second.exec) hipGraphExecDestroy(g.second.exec);
   if (h->cap_stream) hipStreamDestroy(h->cap_stream);
+  if (h->dec_evt) hipEventDestroy(h->dec_evt);
   if (getenv("GAM_GRAPH_DEBUG")) fprintf(stderr, "[gam] graph replays %ld, failed captures %ld\n", h->graph_replays, h->graph_captures_failed);
   delete h;
 }
@@ -1292,6 +1323,8 @@ static int ctc_logits(gam_handle* h, const float* encoded, int B, int64_t Tp, hi
 
 int gam_ctc_head(gam_handle* h, const float* encoded, int B, int64_t Tp, float* log_probs, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (!h) return -1;
+  DecodeScope ds(h, s);
   if (int r = ctc_logits(h, encoded, B, Tp, s)) return r;
   const int V = h->cfg.num_classes, rows = (int)(B * Tp);
   ProfScope ps(h, s, GAM_PF_DECODE, (double)rows * V * 8.0);
@@ -1303,6 +1336,8 @@ int gam_ctc_head(gam_handle* h, const float* encoded, int B, int64_t Tp, float* 
 int gam_ctc_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len, int B, int64_t Tp, int32_t* ids,
                    int32_t* frames, int32_t* counts, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (!h) return -1;
+  DecodeScope ds(h, s);
   if (int r = ctc_logits(h, encoded, B, Tp, s)) return r;
   const int V = h->cfg.num_classes;
   const size_t sm = ((size_t)Tp + GAM_CTC_NT / 64 + 8) * sizeof(int);
@@ -1313,6 +1348,37 @@ int gam_ctc_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len, 
   return 0;
 }
 
+#if GAM_RC_AUDIT
+// diagnosis build: print what the PREVIOUS cluster decode's audit logged (called before the next decode reuses the log, and at destroy --
+// never right behind the launch: a host sync there would remove the very overlap under test)
+static int audit_dump(gam_handle* h) {
+  if (h->rnnt_audit.p == nullptr || !h->audit_pending) return 0;
+  h->audit_pending = false;
+  static std::vector<int> au(16 + 12 * GAM_RC_AUDIT_CAP);
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(au.data(), h->rnnt_audit.p, 64, hipMemcpyDeviceToHost));
+  const int n = au[0];
+  h->audit_decodes++;
+  if (n > 0) {
+    h->audit_hit_decodes++;
+    const int m = n < GAM_RC_AUDIT_CAP ? n : GAM_RC_AUDIT_CAP;
+    HIPCHK(h, hipMemcpy(au.data(), h->rnnt_audit.p, (16 + 12 * (size_t)m) * sizeof(int), hipMemcpyDeviceToHost));
+    int by_site[16] = {0};
+    for (int k = 0; k < m; ++k) by_site[au[16 + 12 * k] & 15]++;
+    fprintf(stderr, "[gam-audit] decode %ld C=%d entries %d; by site:", h->audit_decodes, h->audit_last_c, n);
+    for (int k = 1; k < 16; ++k) if (by_site[k]) fprintf(stderr, " s%d=%d", k, by_site[k]);
+    fprintf(stderr, "\n");
+    for (int k = 0; k < m && k < 24; ++k) {
+      const int* e = au.data() + 16 + 12 * k;
+      float x0, x1; memcpy(&x0, e + 6, 4); memcpy(&x1, e + 7, 4);
+      fprintf(stderr, "[gam-audit]   site %d utt %d member %d xc %d tid %d idx %d: %.9g (%08x) vs %.9g (%08x)  aux %08x %08x\n", e[0], e[1], e[2], e[3], e[4], e[5],
+              x0, (unsigned)e[6], x1, (unsigned)e[7], (unsigned)e[8], (unsigned)e[9]);
+    }
+  }
+  return 0;
+}
+#endif
+
 int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len, int B, int64_t Tp, int max_symbols,
                     int32_t* ids, int32_t* frames, int32_t* counts, float* logits_dump, int32_t* dump_count, int dump_cap,
                     void* stream) {
@@ -1321,6 +1387,7 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
   if (B <= 0 || Tp <= 0 || max_symbols <= 0) return fail(h, -1, "bad arguments");
   hipStream_t s = (hipStream_t)stream;
   HIPCHK(h, hipSetDevice(h->device));
+  DecodeScope ds(h, s);
   const gam_config& c = h->cfg;
   const int D = c.d_model, JH = c.joint_hidden;
   if (int r = to_tokens(h, encoded, B, Tp, s)) return r;
@@ -1369,14 +1436,10 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
       memset(&ca, 0, sizeof ca);
       ca.a = a; ca.whh_q = h->lstm_whh_q; ca.wpred_q = h->jn_pred_q; ca.C = C;
       ca.force_dead = h->rnnt_force_timeout;
-      { const char* e = getenv("GAM_RNNT_DBG"); ca.dbg = e ? atoi(e) : 0; }
       const int nI = gam_cdiv(a.H, C), need = gam_cdiv(4 * nI, 256);
       int nr = need <= 1 ? 1 : (need <= 2 ? 2 : (need <= 3 ? 3 : (need <= 5 ? 5 : 8)));
-      if (getenv("GAM_RNNT_DBG") && (atoi(getenv("GAM_RNNT_DBG")) & 4)) nr = 8;
       const int nV = gam_cdiv(gam_cdiv(a.V, C), 16) * 16;
       ca.wout_slice_in_lds = (size_t)nV * (JH + 4) * 4 + gam_rnnt_cluster_smem(a.H, JH, a.V, C, nr, 0) <= 96 * 1024 ? 1 : 0;
-      if (ca.dbg & 2) ca.wout_slice_in_lds = 0;
-      if (ca.dbg & 8) ca.wout_slice_in_lds = 1;
       ca.wpred_slice_in_lds = gam_rnnt_cluster_smem(a.H, JH, a.V, C, nr, ca.wout_slice_in_lds, 1) <= 150 * 1024 ? 1 : 0;
       size_t sm = gam_rnnt_cluster_smem(a.H, JH, a.V, C, nr, ca.wout_slice_in_lds, ca.wpred_slice_in_lds);
       // A decode workgroup OWNS its compute unit: it asks for the CU's whole LDS (160 KB), so no other workgroup that uses LDS
@@ -1386,7 +1449,7 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
       // both fit) came out with a slightly perturbed predictor state in 5-30 % of the launches -- never with the GPU to
       // itself, never beside the 112-128 KB tiles (which cannot share a CU with it), never with this line.  The grid is at
       // most one workgroup per CU anyway (C is chosen that way), so the claim costs nothing.
-      if ((h->rnnt_exclusive || (ca.dbg & 16)) && sm <= 160 * 1024) sm = 160 * 1024;
+      if (h->rnnt_exclusive && sm <= 160 * 1024) sm = 160 * 1024;
       const size_t xg = gam_rnnt_cluster_xgranules(a.H, JH, C) * (size_t)B;
       if (sm <= 160 * 1024 && need <= 8) {
         if (int r = ensure(h, h->rnnt_x, xg * 2 + 64)) return r;   // (floats: 2 per granule) + status word
@@ -1394,15 +1457,26 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
         ca.xbuf = reinterpret_cast<unsigned long long*>(h->rnnt_x.p);
         ca.status = reinterpret_cast<int*>(h->rnnt_x.p + xg * 2);
         const dim3 grid(8 * nu8 * C);
+#if GAM_RC_AUDIT
+        if (int r = audit_dump(h)) return r;
+        h->audit_pending = true; h->audit_last_c = C;
+        if (int r = ensure(h, h->rnnt_audit, 16 + 12 * GAM_RC_AUDIT_CAP)) return r;
+        HIPCHK(h, hipMemsetAsync(h->rnnt_audit.p, 0, 64, s));
+        ca.audit = reinterpret_cast<int*>(h->rnnt_audit.p);
+#endif
         // Cooperative launch: the runtime REFUSES a grid that cannot be co-resident on this device (occupancy x CUs)
         // instead of letting resident members spin on absent ones; what it cannot see (CUs held by another queue) is
         // what the bounded spins + the repair pass below are for.
         const bool coop = h->rnnt_coop != 0;
         const void* kern = nullptr;
-        static std::atomic<unsigned long long> at1{0}, at2{0}, at3{0}, at5{0}, at8{0}, at1r{0};
+        static std::atomic<unsigned long long> at1{0}, at2{0}, at3{0}, at5{0}, at8{0}, at1r{0}, at2c{0}, at3c{0}, at5c{0};
         std::atomic<unsigned long long>* at = nullptr;
         const bool resident = nr == 1 && a.H == 320 && JH == 320;   // W_hh rows register-resident (gam_decode_cluster.h RESQ)
+        const bool h320 = a.H == 320 && JH == 320;      // compile-time sizes (the published heads)
         if (resident) { kern = reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<1, 80>); at = &at1r; }
+        else if (h320 && nr == 2) { kern = reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<2, 0, 320>); at = &at2c; }
+        else if (h320 && nr == 3) { kern = reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<3, 0, 320>); at = &at3c; }
+        else if (h320 && nr == 5) { kern = reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<5, 0, 320>); at = &at5c; }
         else switch (nr) {
           case 1: kern = reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<1>); at = &at1; break;
           case 2: kern = reinterpret_cast<const void*>(gam_rnnt_cluster_kernel<2>); at = &at2; break;
@@ -1466,6 +1540,7 @@ int gam_rnnt_joint(gam_handle* h, const float* enc, const float* dec, int B, int
   const size_t rows = (size_t)B * T * U;
   if (rows * std::max(JH, V) > ((size_t)1 << 31)) return fail(h, -1, "gam_rnnt_joint: B x T x U = %zu rows is too large for one call", rows);
   hipStream_t s = (hipStream_t)stream;
+  DecodeScope ds(h, s);
   if (int r = ensure(h, h->encp, (size_t)B * T * JH)) return r;
   if (int r = ensure(h, h->jp, (size_t)B * U * JH)) return r;
   if (int r = ensure(h, h->jz, rows * JH)) return r;
@@ -1605,6 +1680,8 @@ int gam_set_rnnt_cluster(gam_handle* h, int workgroups_per_utterance) {
   h->rnnt_cluster = workgroups_per_utterance;
   return 0;
 }
+
+int gam_get_rnnt_cluster(gam_handle* h) { return h ? h->rnnt_cluster : -2; }
 
 int gam_range_flag(gam_handle* h, int* flag_host, void* stream) {
   if (!h || !flag_host) return -1;

@@ -159,6 +159,7 @@ __device__ __forceinline__ f32x4 gam_rc_lds4(const float* p) {
 __device__ __forceinline__ f32x4 gam_rc_glb4(const float* p) {
   return *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>((__attribute__((address_space(1))) const void*)(p));
 }
+__device__ __forceinline__ float gam_rc_glb1(const float* p) { return *p; }
 
 static inline size_t gam_rnnt_smem(int H, int JH, int V, int wout_in_lds, int L = 1) {
   const int vp = (V + 15) / 16 * 16;

@@ -42,7 +42,7 @@ struct GamRnntClusterArgs {
   int wout_slice_in_lds;     // this member's class slice of W_out is cached in LDS
   int wpred_slice_in_lds;    // this member's rows of W_pred are cached in LDS ([H/4][nP][4]): the step's pp no longer waits on L2
   int force_dead;            // test hook (GAM_RNNT_FORCE_TIMEOUT=1): odd utterances report a failed hand-off without decoding
-  int dbg;                   // debug switches (GAM_RNNT_DBG): 1 = window rows by plain loads instead of LDS-DMA
+  int* audit;                // -DGAM_RC_AUDIT=1 builds only: [0] = entries logged, entry k at [16 + 12 k] (null in production)
 };
 
 #define GAM_RC_WIN 16
@@ -61,34 +61,42 @@ enum { T_GATES = 1, T_XH, T_PRED, T_XP, T_Z, T_JOINT, T_XA, T_COMB, T_CTRL, T_RO
 // "every load issued so far has landed", as a compiler barrier too: keeps a batch of independent loads TOGETHER in front of
 // their uses (hipcc otherwise sinks each load into the conditional block that consumes it: one L2 round trip per load)
 #define GAM_RC_LOADS_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-// r05 diagnosis (GAM_RNNT_DBG bit 512 / per-site bits 1 << (12 + site)): drain every counter and barrier at a named point of the round
-#define GAM_RC_PARANOID(site)                                                          \
-  if ((g.dbg & 512) || (g.dbg & (1 << (12 + (site))))) {                              \
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                        \
-    __syncthreads();                                                                   \
+// r06 diagnosis (-DGAM_RC_AUDIT=1, never a production build): every phase of the round is computed TWICE by the same thread from freshly
+// re-read inputs and every piece of LDS-held state is checked against a register copy kept by the thread that wrote it; any difference is
+// logged as (site, utterance, member, exchange counter, thread, index, four words).  Sites: 1 gate row recomputed differs (words: first,
+// second, xor of weight bits xor, xor of h bits xor)   2 gates[] read back != written   3 cell update recomputed differs   4 W_pred row
+// recomputed differs   5 committed h / c in LDS != the writer's register copy (index 0 h, 1 c)   6 candidate h' in LDS != register copy
+// 7 pp in LDS != register copy   8 window row in LDS (LDS-DMA) != the same row loaded from global   9 joint tile recomputed differs
+// 10 gate_tab row re-loaded != the prefetched one
+#ifndef GAM_RC_AUDIT
+#define GAM_RC_AUDIT 0
+#endif
+#define GAM_RC_AUDIT_CAP 4096
+#if GAM_RC_AUDIT
+__device__ __forceinline__ void gam_rc_audit_log(int* au, int site, int b, int cm, unsigned xc, int tid, int idx, float x0, float x1, unsigned x2, unsigned x3) {
+  const int k = atomicAdd(au, 1);
+  if (k < GAM_RC_AUDIT_CAP) {
+    int* e = au + 16 + 12 * k;
+    e[0] = site; e[1] = b; e[2] = cm; e[3] = (int)xc; e[4] = tid; e[5] = idx;
+    e[6] = __float_as_int(x0); e[7] = __float_as_int(x1); e[8] = (int)x2; e[9] = (int)x3;
   }
+}
+#define GAM_RC_LOG(site, idx, x0, x1, x2, x3) gam_rc_audit_log(g.audit, site, b, cm, xc, tid, idx, x0, x1, x2, x3)
+#endif
 
-// (sys: r05 diagnosis switch, GAM_RNNT_DBG bit 128 -- the hand-off at system scope with release / acquire ordering)
-__device__ __forceinline__ void gam_rc_put(unsigned long long* p, float v, unsigned tag, const bool sys = false) {
+__device__ __forceinline__ void gam_rc_put(unsigned long long* p, float v, unsigned tag) {
   const unsigned long long w = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
-  if (sys) __hip_atomic_store(p, w, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  else __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // poll granule p0 and (when ``two``) p1 until their tags match, both loads in flight: one L2 round trip instead of two
 // for the threads that own two granules of a 320-wide exchange; false on timeout / launch-wide abort
 __device__ __forceinline__ bool gam_rc_get2(const unsigned long long* p0, const unsigned long long* p1, bool two, unsigned tag,
-                                            float& v0, float& v1, int* status, const bool sys = false) {
+                                            float& v0, float& v1, int* status) {
   long long t_end = 0;
   bool d0 = false, d1 = !two;
   for (unsigned spin = 0;; ++spin) {
-    unsigned long long g0, g1;
-    if (sys) {
-      g0 = __hip_atomic_load(p0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-      g1 = __hip_atomic_load(two ? p1 : p0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-    } else {
-      g0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      g1 = __hip_atomic_load(two ? p1 : p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    const unsigned long long g0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long g1 = __hip_atomic_load(two ? p1 : p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (!d0 && (unsigned)(g0 >> 32) == tag) { v0 = __uint_as_float((unsigned)g0); d0 = true; }
     if (!d1 && (unsigned)(g1 >> 32) == tag) { v1 = __uint_as_float((unsigned)g1); d1 = true; }
     if (d0 && d1) return true;
@@ -119,7 +127,9 @@ __host__ __device__ static inline size_t gam_rnnt_cluster_xgranules(int H, int J
 // NR: gate-row slots per thread, 4 * ceil(H / C) <= 256 * NR.  RESQ > 0 (only with NR == 1): H == 4 * RESQ and the
 // thread keeps its gate row of W_hh (RESQ x 16 bytes) in registers for the whole decode -- at C >= 5 and H = 320 that is
 // 320 VGPRs of the 512 a one-wave-per-SIMD workgroup owns, and the LSTM step stops touching L2 altogether.
-template <int NR, int RESQ = 0>
+// HC > 0: pred_hidden == joint_hidden == HC at compile time (every published RNN-T head: 320) -- the sizes, strides and trip counts become
+// immediates instead of ~250 scalar registers' worth of spilled loop state (r06: .sgpr_spill_count 363-383 -> see profiles/r06_decode_sgpr.txt)
+template <int NR, int RESQ = 0, int HC = 0>
 __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArgs g) {
   extern __shared__ __attribute__((aligned(16))) float gam_smem_rc[];
   const GamRnntArgs& a = g.a;
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
   const int b = (slot / C) * 8 + xcd, cm = slot % C;
   if (b >= a.B) return;   // (whole clusters drop out together)
   // (the resident kernel is launched only for H == JH == 4 RESQ: compile-time sizes free ~100 scalar registers)
-  const int H = RESQ > 0 ? 4 * RESQ : a.H, JH = RESQ > 0 ? 4 * RESQ : a.JH, V = a.V, blank = a.V - 1;
+  const int H = RESQ > 0 ? 4 * RESQ : (HC > 0 ? HC : a.H), JH = RESQ > 0 ? 4 * RESQ : (HC > 0 ? HC : a.JH), V = a.V, blank = a.V - 1;
   const int nI = (H + C - 1) / C, i0 = cm * nI, i1 = i0 + nI < H ? i0 + nI : H;        // my hidden units
   const int nP = (JH + C - 1) / C, r0 = cm * nP, r1 = r0 + nP < JH ? r0 + nP : JH;     // my rows of W_pred
   const int nV = ((V + C - 1) / C + 15) / 16 * 16, v0 = cm * nV, v1 = v0 + nV < V ? v0 + nV : V;   // my classes
@@ -161,11 +171,6 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
   unsigned long long* xp = xh + 2 * H;                                                  // [2][JH]
   unsigned long long* xa = xp + 2 * JH;                                                 // [2][C][WIN][3]
 
-#if defined(GAM_RC_FULLREGS) && GAM_RC_FULLREGS
-  // r05 diagnosis build only (-DGAM_RC_FULLREGS=1): touching the last accumulation register makes the wave's allocation the whole
-  // 512-entry register file of its SIMD, so no other wave can be placed beside it on that SIMD (the LDS / CU can still be shared)
-  asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
-#endif
   for (int i = tid; i < H; i += 256) { h_s[i] = 0.f; c_s[i] = 0.f; }
   if (tid == 0) dead_s[0] = 0;
   if (wout_l != nullptr)
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
   f32x4 wres[RESQ > 0 ? RESQ : 1];
   if constexpr (RESQ > 0) {
 #pragma unroll
-    for (int q = 0; q < RESQ; ++q) wres[q] = *reinterpret_cast<const f32x4*>(g.whh_q + ((size_t)q * 4 * H + grow[0]) * 4);
+    for (int q = 0; q < RESQ; ++q) wres[q] = gam_rc_glb4(g.whh_q + ((size_t)q * 4 * H + grow[0]) * 4);
   }
 
   // encoder-projection rows of the 16-frame window starting at frame tw, straight into LDS (global_load_lds_dwordx4:
@@ -206,10 +211,6 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       const int f = idx / JQ, q = idx - f * JQ;
       int tt = tw + (f < Wn ? f : Wn - 1);
       tt = tt < 0 ? 0 : (tt < a.Tp ? tt : a.Tp - 1);
-      if (g.dbg & 1) {
-        *reinterpret_cast<f32x4*>(zenc + c * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(a.encp + ((size_t)b * a.Tp + tt) * JH + 4 * q);
-        continue;
-      }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.encp + ((size_t)b * a.Tp + tt) * JH + 4 * q),
                                        (__attribute__((address_space(3))) void*)(zenc + c * 256), 16, 0, 0);
     }
@@ -218,14 +219,16 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
   int label = V;       // gate_tab row V: zero embedding (predict(None, None), decoder.py:97-100)
   float tabv[NR];      // gate_tab[label] of my rows: fetched as soon as the label is known (end of the round that emitted it)
 #pragma unroll
-  for (int j = 0; j < NR; ++j) tabv[j] = a.gate_tab[(size_t)label * 4 * H + grow[j]];
+  for (int j = 0; j < NR; ++j) tabv[j] = gam_rc_glb1(a.gate_tab + (size_t)label * 4 * H + grow[j]);
   int n_out = 0, n_dump = 0;
   int t = 0, sym = 0;
   bool need_pred = true;
   unsigned xc = 0;     // exchange counter = tag
+#if GAM_RC_AUDIT
+  float au_h[2] = {0.f, 0.f}, au_c[2] = {0.f, 0.f}, au_hn[2] = {0.f, 0.f}, au_cn[2] = {0.f, 0.f}, au_pp[2] = {0.f, 0.f};   // (nI, nP <= 512)
+#endif
   int par_h = 0, par_p = 0, par_a = 0;
   bool dead = g.force_dead && (b & 1);
-  const bool sysx = (g.dbg & 128) != 0;
 
 #if GAM_RC_TIMING
   long long tacc[12] = {0}, tlast = wall_clock64();
@@ -235,6 +238,20 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
     tacc[T_ROUNDS] += 1;
 #endif
     if (need_pred) {
+#if GAM_RC_AUDIT
+      {
+        int k = 0;
+        for (int ii = tid; i0 + ii < i1; ii += 256, ++k) {
+          if (__float_as_uint(h_s[i0 + ii]) != __float_as_uint(au_h[k])) GAM_RC_LOG(5, 2 * ii, h_s[i0 + ii], au_h[k], 0u, 0u);
+          if (__float_as_uint(c_s[ii]) != __float_as_uint(au_c[k])) GAM_RC_LOG(5, 2 * ii + 1, c_s[ii], au_c[k], 0u, 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          const float tv = a.gate_tab[(size_t)label * 4 * H + grow[j]];
+          if (__float_as_uint(tv) != __float_as_uint(tabv[j])) GAM_RC_LOG(10, j, tv, tabv[j], (unsigned)label, 0u);
+        }
+      }
+#endif
       // ---- LSTM gates of my units: tab[label] + W_hh.h, k ascending (same fmaf chain as the 1-workgroup kernel)
       {
         float acc[NR];
@@ -254,13 +271,14 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
         // float4 loads in flight per row slot: the step is L2-LATENCY bound (each batch of loads is one round trip),
         // so as many as the registers hold -- ~160 VGPRs of weights per thread
         constexpr int KU = NR == 1 ? 40 : (NR == 2 ? 20 : (NR == 3 ? 12 : (NR == 5 ? 8 : 4)));
-        for (int q0 = 0; q0 < HQ; q0 += KU) {
+#pragma unroll 1
+        for (int q0 = 0; q0 < HQ; q0 += KU) {   // (one batch of loads per trip also when H is a compile-time constant)
           f32x4 w[KU][NR];
 #pragma unroll
           for (int u = 0; u < KU; ++u) {
             const int q = q0 + u < HQ ? q0 + u : HQ - 1;
 #pragma unroll
-            for (int j = 0; j < NR; ++j) w[u][j] = *reinterpret_cast<const f32x4*>(g.whh_q + ((size_t)q * 4 * H + grow[j]) * 4);
+            for (int j = 0; j < NR; ++j) w[u][j] = gam_rc_glb4(g.whh_q + ((size_t)q * 4 * H + grow[j]) * 4);
           }
 #pragma unroll
           for (int u = 0; u < KU; ++u) {
@@ -277,13 +295,59 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
           }
         }
         }
+#if GAM_RC_AUDIT
+        if constexpr (RESQ == 0) {   // second pass: the same sums from re-loaded weights and re-read h
+          float acc2[NR];
+          unsigned wx[2] = {0u, 0u}, hx[2] = {0u, 0u};
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc2[j] = tabv[j];
+          constexpr int KU2 = NR == 1 ? 40 : (NR == 2 ? 20 : (NR == 3 ? 12 : (NR == 5 ? 8 : 4)));
+          for (int pass = 0; pass < 2; ++pass) {   // pass 0 recomputes; pass 1 only re-reads (a third look at the same words)
+            for (int q0 = 0; q0 < HQ; q0 += KU2) {
+              f32x4 w[KU2][NR];
+#pragma unroll
+              for (int u = 0; u < KU2; ++u) {
+                const int q = q0 + u < HQ ? q0 + u : HQ - 1;
+#pragma unroll
+                for (int j = 0; j < NR; ++j) w[u][j] = gam_rc_glb4(g.whh_q + ((size_t)q * 4 * H + grow[j]) * 4);
+              }
+#pragma unroll
+              for (int u = 0; u < KU2; ++u) {
+                if (q0 + u < HQ) {
+                  const f32x4 hv = *reinterpret_cast<const f32x4*>(h_s + 4 * (q0 + u));
+                  hx[pass] ^= __float_as_uint(hv.x) ^ (__float_as_uint(hv.y) * 3u) ^ (__float_as_uint(hv.z) * 5u) ^ (__float_as_uint(hv.w) * 7u);
+#pragma unroll
+                  for (int j = 0; j < NR; ++j) {
+                    wx[pass] ^= (__float_as_uint(w[u][j].x) ^ (__float_as_uint(w[u][j].y) * 3u) ^ (__float_as_uint(w[u][j].z) * 5u) ^ (__float_as_uint(w[u][j].w) * 7u)) * (unsigned)(2 * j + 1);
+                    if (pass == 0) {
+                      acc2[j] = fmaf(w[u][j].x, hv.x, acc2[j]);
+                      acc2[j] = fmaf(w[u][j].y, hv.y, acc2[j]);
+                      acc2[j] = fmaf(w[u][j].z, hv.z, acc2[j]);
+                      acc2[j] = fmaf(w[u][j].w, hv.w, acc2[j]);
+                    }
+                  }
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int j = 0; j < NR; ++j)
+            if (gok[j] && (__float_as_uint(acc2[j]) != __float_as_uint(acc[j]) || wx[0] != wx[1] || hx[0] != hx[1]))
+              GAM_RC_LOG(1, j, acc[j], acc2[j], wx[0] ^ wx[1], hx[0] ^ hx[1]);
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < NR; ++j)
           if (gok[j]) gates[tid + 256 * j] = acc[j];
+#if GAM_RC_AUDIT
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+          if (gok[j] && __float_as_uint(gates[tid + 256 * j]) != __float_as_uint(acc[j])) GAM_RC_LOG(2, j, gates[tid + 256 * j], acc[j], 0u, 0u);
+#endif
       }
       __syncthreads();
     GAM_RC_MARK(T_GATES);
-    GAM_RC_PARANOID(0);
       ++xc;
       for (int ii = tid; i0 + ii < i1; ii += 256) {   // cell update of my units (gate order i, f, g, o)
         const float ig = gam_sigmoid_exact(gates[ii]), fg = gam_sigmoid_exact(gates[nI + ii]);
@@ -291,14 +355,26 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
         const float cn = fg * c_s[ii] + ig * gg;
         const float hn = og * tanhf(cn);
         cn_s[ii] = cn;
-        if (C > 1) gam_rc_put(xh + par_h * H + i0 + ii, hn, xc, sysx);
+#if GAM_RC_AUDIT
+        {
+          const volatile float* gv = gates;
+          const volatile float* cv = c_s;
+          const float ig2 = gam_sigmoid_exact(gv[ii]), fg2 = gam_sigmoid_exact(gv[nI + ii]);
+          const float gg2 = tanhf(gv[2 * nI + ii]), og2 = gam_sigmoid_exact(gv[3 * nI + ii]);
+          const float cn2 = fg2 * cv[ii] + ig2 * gg2;
+          const float hn2 = og2 * tanhf(cn2);
+          if (__float_as_uint(cn2) != __float_as_uint(cn) || __float_as_uint(hn2) != __float_as_uint(hn)) GAM_RC_LOG(3, ii, hn, hn2, __float_as_uint(cn), __float_as_uint(cn2));
+          au_hn[ii >> 8] = hn; au_cn[ii >> 8] = cn;
+        }
+#endif
+        if (C > 1) gam_rc_put(xh + par_h * H + i0 + ii, hn, xc);
         else hn_s[i0 + ii] = hn;
       }
       if (C > 1) {
         for (int i = tid; i < H; i += 512) {
           float va = 0.f, vb = 0.f;
           const bool two = i + 256 < H;
-          if (!gam_rc_get2(xh + par_h * H + i, xh + par_h * H + i + 256, two, xc, va, vb, g.status, sysx)) { dead_s[0] = 1; va = vb = 0.f; }
+          if (!gam_rc_get2(xh + par_h * H + i, xh + par_h * H + i + 256, two, xc, va, vb, g.status)) { dead_s[0] = 1; va = vb = 0.f; }
           hn_s[i] = va;
           if (two) hn_s[i + 256] = vb;
         }
@@ -306,14 +382,20 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       }
       __syncthreads();
     GAM_RC_MARK(T_XH);
-    GAM_RC_PARANOID(1);
+#if GAM_RC_AUDIT
+      {
+        int k = 0;
+        for (int ii = tid; i0 + ii < i1; ii += 256, ++k)
+          if (__float_as_uint(hn_s[i0 + ii]) != __float_as_uint(au_hn[k])) GAM_RC_LOG(6, ii, hn_s[i0 + ii], au_hn[k], 0u, 0u);
+      }
+#endif
       if (dead_s[0]) { dead = true; break; }
       // ---- my rows of W_pred.h' + b_pred
       {
         if (P == 1) {
           for (int rr = tid; r0 + rr < r1; rr += 256) {
             const int r = r0 + rr;
-            float acc = a.bpred[r];
+            float acc = gam_rc_glb1(a.bpred + r);
             for (int q0 = 0; q0 < HQ; q0 += 16) {
               f32x4 w[16];
 #pragma unroll
@@ -330,13 +412,34 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
                 }
             }
             red[rr] = acc;
+#if GAM_RC_AUDIT
+            {
+              float acc2 = a.bpred[r];
+              for (int q0 = 0; q0 < HQ; q0 += 16) {
+                f32x4 w[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                  const int q = q0 + u < HQ ? q0 + u : HQ - 1;
+                  if (wpl != nullptr) w[u] = gam_rc_lds4(wpl + ((size_t)q * nP + rr) * 4);
+                  else w[u] = gam_rc_glb4(g.wpred_q + ((size_t)q * JH + r) * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                  if (q0 + u < HQ) {
+                    const f32x4 hv = *reinterpret_cast<const f32x4*>(hn_s + 4 * (q0 + u));
+                    acc2 = fmaf(w[u].x, hv.x, acc2); acc2 = fmaf(w[u].y, hv.y, acc2); acc2 = fmaf(w[u].z, hv.z, acc2); acc2 = fmaf(w[u].w, hv.w, acc2);
+                  }
+              }
+              if (__float_as_uint(acc2) != __float_as_uint(acc)) GAM_RC_LOG(4, rr, acc, acc2, 0u, 0u);
+            }
+#endif
           }
         } else {
           const int rr = tid % nP, part = tid / nP;
           if (part < P && r0 + rr < r1) {
             const int r = r0 + rr;
             const int qa = part * HQ / P, qb = (part + 1) * HQ / P;
-            float acc = part == 0 ? a.bpred[r] : 0.f;
+            float acc = part == 0 ? gam_rc_glb1(a.bpred + r) : 0.f;
             for (int q0 = qa; q0 < qb; q0 += 16) {
               f32x4 w[16];
 #pragma unroll
@@ -358,19 +461,21 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       }
       __syncthreads();
     GAM_RC_MARK(T_PRED);
-    GAM_RC_PARANOID(2);
       ++xc;
       for (int rr = tid; r0 + rr < r1; rr += 256) {
         float v = red[rr];
         for (int p = 1; p < P; ++p) v += red[p * nP + rr];
-        if (C > 1) gam_rc_put(xp + par_p * JH + r0 + rr, v, xc, sysx);
+        if (C > 1) gam_rc_put(xp + par_p * JH + r0 + rr, v, xc);
         else pp[r0 + rr] = v;
+#if GAM_RC_AUDIT
+        au_pp[rr >> 8] = v;
+#endif
       }
       if (C > 1) {
         for (int i = tid; i < JH; i += 512) {
           float va = 0.f, vb = 0.f;
           const bool two = i + 256 < JH;
-          if (!gam_rc_get2(xp + par_p * JH + i, xp + par_p * JH + i + 256, two, xc, va, vb, g.status, sysx)) { dead_s[0] = 1; va = vb = 0.f; }
+          if (!gam_rc_get2(xp + par_p * JH + i, xp + par_p * JH + i + 256, two, xc, va, vb, g.status)) { dead_s[0] = 1; va = vb = 0.f; }
           pp[i] = va;
           if (two) pp[i + 256] = vb;
         }
@@ -379,7 +484,6 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       need_pred = false;
       __syncthreads();
     GAM_RC_MARK(T_XP);
-    GAM_RC_PARANOID(3);
       if (dead_s[0]) { dead = true; break; }
     }
 
@@ -388,6 +492,24 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
     // (the window's encoder-projection rows were fetched when t was decided, at the end of the previous round)
     __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0): my wave's LDS-DMA loads have landed ...
     __syncthreads();                      // ... and so have everyone else's
+#if GAM_RC_AUDIT
+    {
+      int k = 0;
+      for (int rr = tid; r0 + rr < r1; rr += 256, ++k)
+        if (__float_as_uint(pp[r0 + rr]) != __float_as_uint(au_pp[k])) GAM_RC_LOG(7, rr, pp[r0 + rr], au_pp[k], 0u, 0u);
+      const int Wn = len - t < GAM_RC_WIN ? len - t : GAM_RC_WIN;
+      for (int idx = tid; idx < GAM_RC_WIN * JQ; idx += 256) {
+        const int f = idx / JQ, q = idx - f * JQ;
+        int tt = t + (f < Wn ? f : Wn - 1);
+        tt = tt < 0 ? 0 : (tt < a.Tp ? tt : a.Tp - 1);
+        const f32x4 ev = *reinterpret_cast<const f32x4*>(zenc + 4 * idx);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(a.encp + ((size_t)b * a.Tp + tt) * JH + 4 * q);
+        if (__float_as_uint(ev.x) != __float_as_uint(gv.x) || __float_as_uint(ev.y) != __float_as_uint(gv.y) || __float_as_uint(ev.z) != __float_as_uint(gv.z) ||
+            __float_as_uint(ev.w) != __float_as_uint(gv.w))
+          GAM_RC_LOG(8, idx, ev.x, gv.x, (unsigned)t, (unsigned)tt);
+      }
+    }
+#endif
     for (int idx = tid; idx < GAM_RC_WIN * JQ; idx += 256) {
       const int f = idx / JQ, q = idx - f * JQ;
       const f32x4 ev = *reinterpret_cast<const f32x4*>(zenc + 4 * idx);
@@ -397,7 +519,6 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
     }
     __syncthreads();
     GAM_RC_MARK(T_Z);
-    GAM_RC_PARANOID(4);
     // logits[f][v] = bout[v] + sum_k z[f][k] wout[v][k] for my classes: one 16x16 MFMA tile per 16 classes
     for (int nt = wave; v0 + nt * 16 < v1; nt += 4) {
       const int v = v0 + nt * 16 + li;
@@ -433,15 +554,26 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       if (wout_l != nullptr) tile([](const float* p) { return gam_rc_lds4(p); }, wout_l + (size_t)(vc - v0) * WLD + 4 * lg4, false);
       else tile([](const float* p) { return gam_rc_glb4(p); }, a.wout + (size_t)vc * JH + 4 * lg4, true);
       acc = (acc + acc1) + (acc2 + acc3);
+#if GAM_RC_AUDIT
+      {
+        const f32x4 first = acc;
+        acc = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1 = acc; acc2 = acc; acc3 = acc;
+        if (wout_l != nullptr) tile([](const float* p) { return gam_rc_lds4(p); }, wout_l + (size_t)(vc - v0) * WLD + 4 * lg4, false);
+        else tile([](const float* p) { return gam_rc_glb4(p); }, a.wout + (size_t)vc * JH + 4 * lg4, true);
+        acc = (acc + acc1) + (acc2 + acc3);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (__float_as_uint(first[r]) != __float_as_uint(acc[r])) GAM_RC_LOG(9, nt * 64 + lane, first[r], acc[r], (unsigned)r, 0u);
+      }
+#endif
       if (v < v1) {   // C/D: col = lane&15 = class, row = 4*(lane>>4) + r = frame
-        const float bo = a.bout[v];
+        const float bo = gam_rc_glb1(a.bout + v);
 #pragma unroll
         for (int r = 0; r < 4; ++r) lgw[(4 * lg4 + r) * LLD + (v - v0)] = acc[r] + bo;
       }
     }
     __syncthreads();
     GAM_RC_MARK(T_JOINT);
-    GAM_RC_PARANOID(5);
     // per-frame (max, first argmax, sum-exp) over my classes: 16 lanes per frame, wave w takes frames 4w .. 4w+3
     ++xc;
     const int NG = a.dump != nullptr ? 3 : 2;   // (the sum-exp is only exchanged when log-probs are dumped)
@@ -471,9 +603,9 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       if (li == 0) {
         if (C > 1) {
           unsigned long long* q = xa + (((size_t)par_a * C + cm) * GAM_RC_WIN + f) * 3;
-          gam_rc_put(q + 0, best, xc, sysx);
-          gam_rc_put(q + 1, __int_as_float(bi), xc, sysx);
-          if (NG == 3) gam_rc_put(q + 2, se, xc, sysx);
+          gam_rc_put(q + 0, best, xc);
+          gam_rc_put(q + 1, __int_as_float(bi), xc);
+          if (NG == 3) gam_rc_put(q + 2, se, xc);
         } else {
           apart[f * 3 + 0] = best; apart[f * 3 + 1] = __int_as_float(bi); apart[f * 3 + 2] = se;
         }
@@ -486,7 +618,7 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
         const bool two = i + 256 < n;
         const int ia = i / NG * 3 + i % NG, ib = (i + 256) / NG * 3 + (i + 256) % NG;
         const unsigned long long* base = xa + (size_t)par_a * C * GAM_RC_WIN * 3;
-        if (!gam_rc_get2(base + ia, base + ib, two, xc, va, vb, g.status, sysx)) { dead_s[0] = 1; va = vb = 0.f; }
+        if (!gam_rc_get2(base + ia, base + ib, two, xc, va, vb, g.status)) { dead_s[0] = 1; va = vb = 0.f; }
         apart[ia] = va;
         if (two) apart[ib] = vb;
       }
@@ -494,7 +626,6 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
     }
     __syncthreads();
     GAM_RC_MARK(T_XA);
-    GAM_RC_PARANOID(6);
     if (dead_s[0]) { dead = true; break; }
     // combine the members' slices (ascending class order: the first maximum wins).  Every wave does it for all 16
     // frames (lane & 15 = frame), so the window's verdict needs no further barrier: a ballot gives the first
@@ -523,7 +654,6 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       }
     }
     GAM_RC_MARK(T_COMB);
-    GAM_RC_PARANOID(7);
     const int n_eval = fstar < W ? fstar + 1 : W;   // joint evaluations the sequential loop performs
     if (a.dump != nullptr) {
       for (int f = 0; f < n_eval; ++f) {
@@ -531,13 +661,6 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
           float* dp = a.dump + ((size_t)b * a.dump_cap + n_dump + f) * V;
           const float lse = lse_s[f];
           for (int vl = tid; v0 + vl < v1; vl += 256) dp[v0 + vl] = lgw[f * LLD + vl] - lse;
-          if ((g.dbg & 64) && cm == 0 && tid == 0 && V >= 12) {   // debug: internals instead of the first log-probs
-            float sh = 0.f, sp = 0.f, se = 0.f, sz = 0.f, sc = 0.f;
-            for (int k = 0; k < H; ++k) sh += h_s[k];
-            for (int k = 0; k < nI; ++k) sc += c_s[k];
-            for (int k = 0; k < JH; ++k) { sp += pp[k]; se += zenc[f * JH + k]; sz += zw[f * ZLD + k]; }
-            dp[0] = sh; dp[1] = sp; dp[2] = se; dp[3] = sz; dp[4] = (float)label; dp[5] = (float)(t + f); dp[6] = sc; dp[7] = tabv[0];
-          }
         }
       }
     }
@@ -557,17 +680,18 @@ __global__ __launch_bounds__(256) void gam_rnnt_cluster_kernel(GamRnntClusterArg
       ++sym;
       label = k;
 #pragma unroll
-      for (int j = 0; j < NR; ++j) tabv[j] = a.gate_tab[(size_t)label * 4 * H + grow[j]];   // lands while the round finishes
+      for (int j = 0; j < NR; ++j) tabv[j] = gam_rc_glb1(a.gate_tab + (size_t)label * 4 * H + grow[j]);   // lands while the round finishes
       { float* x = h_s; h_s = hn_s; hn_s = x; x = c_s; c_s = cn_s; cn_s = x; }   // commit (h', c'): swap the buffers
+#if GAM_RC_AUDIT
+      au_h[0] = au_hn[0]; au_h[1] = au_hn[1]; au_c[0] = au_cn[0]; au_c[1] = au_cn[1];
+#endif
       need_pred = true;
       if (sym >= a.max_symbols) { t = te + 1; sym = 0; }   // frame advances regardless (decoding.py:189-205)
       else t = te;
     }
-    GAM_RC_PARANOID(9);
     if (t < len) fetch_window(t);
     __syncthreads();
     GAM_RC_MARK(T_CTRL);
-    GAM_RC_PARANOID(8);
   }
 #if GAM_RC_TIMING
   if (b == 0 && cm == 0 && tid == 0)

@@ -138,7 +138,9 @@ class HipEngine:
             self._check(rc, f"gam_set_weight({key})")
         self._check(self.lib.gam_finalize(self._h), "gam_finalize")
         import os
-        self._rnnt_cluster_default = int(os.environ.get("GAM_RNNT_CLUSTER", "-1"))   # what gam_create read (restored after an overlapped decode)
+        # the cluster size in force outside an overlapped decode: what gam_create read from the environment (clamped like it does), then
+        # whatever the caller set through set_rnnt_cluster -- an overlapped decode restores THIS, not the environment's value
+        self._rnnt_cluster_user = max(-1, min(8, int(os.environ.get("GAM_RNNT_CLUSTER", "-1"))))
 
     # ------------------------------------------------------------------ utils
     def _check(self, rc: int, what: str) -> None:
@@ -234,6 +236,10 @@ class HipEngine:
             for t in (ids, frames, src):
                 t.record_stream(side)
         else:
+            if ids.is_cuda:
+                # bare tensors carry no completion event: the decode may have run on the engine's side stream, which a .cpu() on the
+                # CURRENT stream is not ordered behind -- wait for the whole device rather than read half-written counts
+                torch.cuda.synchronize(ids.device)
             n = src.cpu().tolist()
             flag = bool(n.pop()) if ext is not None else False
             width = max(n) if n else 0
@@ -318,6 +324,7 @@ class HipEngine:
     def set_rnnt_cluster(self, n: int) -> None:
         """Workgroups per utterance of the cluster decode kernel (gam_set_rnnt_cluster): -1 auto, 0 one-workgroup kernel, 1..8."""
         self._check(self.lib.gam_set_rnnt_cluster(self._h, int(n)), "gam_set_rnnt_cluster")
+        self._rnnt_cluster_user = int(n)
 
     def _decode_side_stream(self) -> "torch.cuda.Stream":
         st = getattr(self, "_side_stream", None)
@@ -342,7 +349,11 @@ class HipEngine:
         return at once -- the caller's next ``frontend`` / ``encode`` on the current stream then runs BESIDE this decode instead of
         behind it (the greedy loop is latency-bound: with the GPU to itself it keeps ~224 CUs resident and idle).
         The range flag is fetched on the CURRENT stream first, so it covers exactly this batch's frontend + encoder (fetched on
-        the side stream it would swallow a flag the next batch's encoder sets meanwhile).  Same kernels, same results."""
+        the side stream it would swallow a flag the next batch's encoder sets meanwhile).  Same kernels; ids are bit-identical to a serial decode
+        AT THE SAME CLUSTER SIZE (tests/test_hip_hardening.py).  The cluster size fixes how a member's sums are partitioned, so a decode with
+        small clusters may resolve a near-tie (top-1 / top-2 margin below ~1e-5) differently from the full-size clusters' -- inside the 1e-3 logit
+        bar, and the reason bench.py and the tests compare overlapped and serial decodes at equal cluster size.  Decode-class calls of one handle
+        are ordered by the library whatever streams they run on (gam_api.hip DecodeScope)."""
         encoded = self._dev(encoded, torch.float32)
         enc_len = self._dev(enc_len, torch.int32)
         b, _, tp = encoded.shape
@@ -354,7 +365,8 @@ class HipEngine:
             with torch.cuda.device(self.device):
                 self._fetch_flag(ext)            # on the launch stream: this batch's own flag (its event is not the decode's)
             side.wait_stream(main)
-            self.set_rnnt_cluster(self.side_cluster(b, side_cus if side_cus > 0 else (96 if self.cfg.num_classes <= 64 else 160)))
+            c_side = self.side_cluster(b, side_cus if side_cus > 0 else (96 if self.cfg.num_classes <= 64 else 160))
+            self._check(self.lib.gam_set_rnnt_cluster(self._h, c_side), "gam_set_rnnt_cluster")     # (for this call only: restored below)
         try:
             with torch.cuda.stream(side) if overlap else torch.cuda.device(self.device):
                 ids = torch.empty((b, cap), dtype=torch.int32, device=self.device)
@@ -376,7 +388,7 @@ class HipEngine:
                     evt, st = self._fetch_flag(ext)
         finally:
             if overlap:
-                self.set_rnnt_cluster(self._rnnt_cluster_default)
+                self._check(self.lib.gam_set_rnnt_cluster(self._h, self._rnnt_cluster_user), "gam_set_rnnt_cluster")
         return Decoded(ids, frames, counts, ext, evt, st, dump, dcount)
 
     def rnnt_predict(self, labels: Optional[Tensor], state: Optional[Tuple[Tensor, Tensor]], batch_size: int = 1):

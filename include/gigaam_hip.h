@@ -115,11 +115,18 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
 /* Workgroups per utterance of the cluster decode kernel behind gam_rnnt_greedy: -1 = as many as the device holds at once
  * (the default: the decode has the GPU to itself), 0 = the one-workgroup-per-utterance kernel, 1..8 = at most that many.
  * A caller that runs the decode of batch n on a side stream BESIDE the encoder of batch n+1 (the product's RNN-T
- * pipelines do, r05: model.launch_batch) asks for small clusters so that the latency-bound decode holds few CUs; results
- * are the same for every setting (tests: C in {0, 1, 2, 3, 5, 8}).  gam_rnnt_greedy is safe to run concurrently with
- * gam_frontend / gam_encode of the SAME handle on another stream (it shares no scratch with them); two decodes of one
- * handle must be stream-ordered.  (Environment GAM_RNNT_CLUSTER sets the initial value.) */
+ * pipelines do, r05: model.launch_batch) asks for small clusters so that the latency-bound decode holds few CUs.  Every
+ * setting holds the reference's bars (ids / frames / step counts exact on the fixtures, log-probs <= 1e-3; tests: C in
+ * {0, 1, 2, 3, 5, 8}) and is bit-reproducible run to run; the setting fixes how a member partitions its sums, so two
+ * DIFFERENT settings may resolve a near-tie (top-1 / top-2 margin ~1e-5) differently.  gam_rnnt_greedy is safe to run
+ * concurrently with gam_frontend / gam_encode of the SAME handle on another stream (it shares no scratch with them).
+ * Decode-class calls of one handle (gam_ctc_head / gam_ctc_greedy / gam_rnnt_greedy / gam_rnnt_joint) share one set of
+ * scratch buffers: the library orders them itself -- a call on a stream other than the previous decode-class call's first
+ * waits for that call's completion event (r06) -- so the caller may put them on any streams; they never run concurrently
+ * with each other.  (Environment GAM_RNNT_CLUSTER sets the initial value, clamped to -1..8.) */
 int gam_set_rnnt_cluster(gam_handle* h, int workgroups_per_utterance);
+/* The setting in force (-1 auto, 0 .. 8); -2 for a NULL handle. */
+int gam_get_rnnt_cluster(gam_handle* h);
 
 /* Debug aid (r05): FNV-1a hash over one of the decode's scratch buffers as it sits in device memory (synchronises the
  * device).  which: 0 = token-major copy of the encoder output, 1 = encoder projection, 2 = hand-off granules, 3 = CTC

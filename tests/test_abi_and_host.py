@@ -25,6 +25,22 @@ def test_library_exports_every_header_symbol():
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
 
 
+def test_device_code_has_no_unreliable_packed_fp32():
+    """r06: a v_pk_{fma,mul,add}_f32 whose low result reads the HIGH register of src1 (op_sel:[x,1,..]) miscomputes lanes 48..63 on MI355X
+    whenever another wave on its SIMD issues MFMAs (tools/pkfma_rule.hip, profiles/r06_pkfma_rule.txt) -- the mechanism behind r05's
+    "co-residency perturbation" of the RNN-T decode.  The shipped library must not contain one (gigaam_amd/build.py gates the build too),
+    and the gate itself must recognise the form."""
+    from gigaam_amd import build
+    assert "-fno-slp-vectorize" in build.FLAGS
+    assert build._RISKY.search("\tv_pk_fma_f32 v[4:5], v[134:135], v[174:175], v[4:5] op_sel:[0,1,0]")
+    assert build._RISKY.search("\tv_pk_mul_f32 v[4:5], v[134:135], v[174:175] op_sel:[0,1]")
+    assert not build._RISKY.search("\tv_pk_fma_f32 v[4:5], v[134:135], v[174:175], v[4:5] op_sel_hi:[1,0,1]")
+    assert not build._RISKY.search("\tv_pk_fma_f32 v[4:5], v[134:135], v[174:175], v[4:5] op_sel:[1,0,1]")
+    assert not build._RISKY.search("\tv_pk_fma_f16 v4, v134, v174, v4 op_sel:[0,1,0]")
+    hits = build.risky_packed_f32(_lib.LIB_PATH)
+    assert hits == [], hits[:10]
+
+
 def test_config_mirror_matches_reference_defaults():
     from gigaam_amd.engine import build_config
     cfg = synth.model_cfg("v2_ctc")

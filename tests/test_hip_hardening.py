@@ -250,32 +250,40 @@ def test_rnnt_decode_overlapped_with_the_next_encoder(model_name, bias):
     assert texts == texts_serial
 
 
-def test_rnnt_decode_is_not_perturbed_by_another_streams_gemm():
-    """r05 regression (profiles/r05_overlap_investigation.txt): an RNN-T cluster decode on a side stream while the launch stream runs
-    the small-tile LDS-DMA GEMM (64-96 KB of LDS per workgroup: it used to fit on a CU BESIDE a 56-120 KB decode workgroup) came out
-    with a perturbed predictor state in 5-30 % of the launches.  Decode workgroups now claim their CU's whole LDS; 150 decodes of a
-    dense (near-tie-rich) batch beside such GEMMs must all be bit-identical to the decode with the GPU to itself."""
+@pytest.mark.parametrize("exclusive", [1, 0])
+def test_rnnt_decode_is_not_perturbed_by_another_streams_gemm(exclusive):
+    """r05 / r06 regression (profiles/r05_overlap_investigation.txt, profiles/r06_INDEX.txt): an RNN-T cluster decode on a side stream while the
+    launch stream runs the small-tile GEMM came out with a perturbed predictor state in 1-30 % of the launches.  r06 found the mechanism: hipcc
+    had packed pairs of gate-row FMA chains into v_pk_fma_f32 with op_sel:[0,1,0], whose low result is wrong in lanes 48..63 whenever another
+    wave on the SIMD issues MFMAs (tools/pkfma_rule.hip).  The library holds no such instruction any more (gigaam_amd/build.py), so the decode
+    must be bit-identical to the one that had the GPU to itself BOTH with the r05 protection (workgroups claim their CU's whole LDS,
+    exclusive = 1, the default) and without it (GAM_RNNT_EXCLUSIVE=0: decode workgroups share CUs with the GEMM's).  With the r05 library the
+    exclusive = 0 leg fails with probability > 0.95 (cluster size 1: 34 of 3000 decodes differed)."""
+    import os
     from gigaam_amd import synth
     from gigaam_amd.engine import HipEngine, build_config
     ck = synth.make_checkpoint("v2_rnnt", seed=1, n_layers=2, rnnt_blank_bias=13.5)
     cfg = ck["cfg"]
-    eng = HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], cfg["head"]), ck["state_dict"], torch.device("cuda:0"))
+    os.environ["GAM_RNNT_EXCLUSIVE"] = str(exclusive)      # (read by gam_create)
+    try:
+        eng = HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], cfg["head"]), ck["state_dict"], torch.device("cuda:0"))
+    finally:
+        del os.environ["GAM_RNNT_EXCLUSIVE"]
     lens = [int(16000 * (1.0 + 0.37 * ((3 * i + 1) % 11))) for i in range(32)]
     wav, wlen = synth.synth_audio(32, max(lens) / 16000.0, seed=301, lengths=lens)
     enc, elen = eng.encode(*eng.frontend(wav, wlen))
     xa = torch.randn(640, 768, device="cuda")
     wa = torch.randn(768, 768, device="cuda") * 0.03
     ref_gemm = eng.op_gemm(xa, wa).clone()
-    for cluster in (2, 1, 4):
+    for cluster, reps in ((1, 300 if exclusive == 0 else 50), (2, 100 if exclusive == 0 else 50), (4, 50)):
         eng.set_rnnt_cluster(cluster)
         alone = HipEngine.collect(eng.rnnt_greedy(enc, elen, 10))[0]
         eng.set_rnnt_cluster(-1)
         assert sum(len(i) for i, _ in alone) > 300
         bad = 0
-        import os
         os.environ["GAM_DEBUG_SIDE_CLUSTER"] = str(cluster)
         try:
-            for _ in range(50):
+            for _ in range(reps):
                 dec = eng.rnnt_greedy(enc, elen, 10, overlap=True)
                 for _ in range(30):
                     out = eng.op_gemm(xa, wa)
@@ -283,4 +291,46 @@ def test_rnnt_decode_is_not_perturbed_by_another_streams_gemm():
                 assert torch.equal(out, ref_gemm)          # (and the GEMM is not perturbed by the decode either)
         finally:
             del os.environ["GAM_DEBUG_SIDE_CLUSTER"]
-        assert bad == 0, (cluster, bad)
+        assert bad == 0, (exclusive, cluster, bad)
+
+
+def test_decodes_on_different_streams_are_ordered_by_the_library():
+    """the decode class owns ONE set of scratch per handle (tok / encp / rnnt_x ...).  An overlapped decode (side stream) followed
+    at once by a serial decode of ANOTHER batch on the launch stream -- what transcribe_longform / run_sharded do for their last batch -- used to
+    have nothing ordering the second behind the first.  gam_api.hip's DecodeScope now makes every decode-class call wait for the previous one's
+    completion event when the streams differ: both decodes must equal their own serial results, also for the CTC head and the joint entry point."""
+    from gigaam_amd import synth
+    from gigaam_amd.engine import HipEngine, build_config
+    ck = synth.make_checkpoint("v2_rnnt", seed=1, n_layers=2, rnnt_blank_bias=13.5)
+    cfg = ck["cfg"]
+    eng = HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], cfg["head"]), ck["state_dict"], torch.device("cuda:0"))
+    lens = [int(16000 * (1.0 + 0.37 * ((3 * i + 1) % 11))) for i in range(32)]
+    wav, wlen = synth.synth_audio(32, max(lens) / 16000.0, seed=301, lengths=lens)
+    enc_big, elen_big = eng.encode(*eng.frontend(wav, wlen))
+    enc_big, elen_big = enc_big.clone(), elen_big.clone()
+    wav1, wlen1 = synth.synth_audio(1, 1.5, seed=77, lengths=[24000])
+    enc_1, elen_1 = eng.encode(*eng.frontend(wav1, wlen1))
+    enc_1, elen_1 = enc_1.clone(), elen_1.clone()
+    eng.set_rnnt_cluster(HipEngine.side_cluster(32, 96))
+    want_big = HipEngine.collect(eng.rnnt_greedy(enc_big, elen_big, 10))[0]
+    eng.set_rnnt_cluster(-1)
+    want_1 = HipEngine.collect(eng.rnnt_greedy(enc_1, elen_1, 10))[0]
+    g, st = eng.rnnt_predict(None, None, 1)
+    want_joint = eng.rnnt_joint(enc_1.transpose(1, 2).contiguous()[:, :4], g[:, None, :]).clone()
+    torch.cuda.synchronize()
+    eng.set_rnnt_cluster(3)      # a caller's own setting survives overlapped decodes (ADVICE r5: it used to be reset to the environment's value)
+    HipEngine.collect(eng.rnnt_greedy(enc_1, elen_1, 10, overlap=True))
+    assert eng.lib.gam_get_rnnt_cluster(eng._h) == 3
+    eng.set_rnnt_cluster(-1)
+    for rep in range(40):
+        big = eng.rnnt_greedy(enc_big, elen_big, 10, overlap=True, side_cus=96)     # slow small clusters on the side stream ...
+        if rep % 2 == 0:
+            one = eng.rnnt_greedy(enc_1, elen_1, 10)                                 # ... and at once a B = 1 decode on the launch stream
+            assert HipEngine.collect(one)[0] == want_1, rep
+        else:
+            got_joint = eng.rnnt_joint(enc_1.transpose(1, 2).contiguous()[:, :4], g[:, None, :])   # (rewrites encp on the launch stream)
+            torch.cuda.synchronize()
+            assert torch.equal(got_joint, want_joint), rep
+        assert HipEngine.collect(big)[0] == want_big, rep
+
+

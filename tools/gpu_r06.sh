@@ -1,0 +1,50 @@
+#!/bin/bash
+# r06 GPU sessions (one stage per gpurun call):  gpurun --timeout 1500 -- 'bash tools/gpu_r06.sh <stage>'
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
+R=$PWD
+STAGE=${1:-s1}
+OUT=$R/gpurun_out/r06_$STAGE; mkdir -p $OUT
+export TMPDIR=/tmp
+repro() {  # name lib env... -- args
+  local name=$1 lib=$2; shift 2
+  ( env GIGAAM_HIP_LIB=$R/gigaam_amd/$lib "$@" ) 2>> $OUT/$name.err | grep -a "REPRO" | tee -a $OUT/repro.txt
+}
+case $STAGE in
+s1)  # the co-residency mechanism: L1-hit canary + the decode reproducer with L1-bypassing weight loads
+  timeout 600 python tools/l1_canary.py 6 2> $OUT/canary.err | tee $OUT/canary.txt
+  repro base   libgigaam_hip.so     GAM_RNNT_EXCLUSIVE=0 timeout 300 python tools/coresidency_repro.py 2,1,4 300 gemm640
+  repro nt     libgigaam_hip_nt.so  GAM_RNNT_EXCLUSIVE=0 timeout 300 python tools/coresidency_repro.py 2,1,4 300 gemm640
+  repro sc1    libgigaam_hip_sc1.so GAM_RNNT_EXCLUSIVE=0 timeout 300 python tools/coresidency_repro.py 2,1,4 300 gemm640
+  repro base2  libgigaam_hip.so     GAM_RNNT_EXCLUSIVE=0 timeout 300 python tools/coresidency_repro.py 2,1 300 gemm640
+  repro legacy libgigaam_hip.so     GAM_RNNT_EXCLUSIVE=0 GAM_SP_MIN_M=1073741824 timeout 300 python tools/coresidency_repro.py 2,1 300 legacy
+  repro attn   libgigaam_hip.so     GAM_RNNT_EXCLUSIVE=0 timeout 300 python tools/coresidency_repro.py 2 300 attention
+  repro none   libgigaam_hip.so     GAM_RNNT_EXCLUSIVE=0 timeout 300 python tools/coresidency_repro.py 2 300 none
+  repro excl   libgigaam_hip.so     GAM_RNNT_EXCLUSIVE=1 timeout 300 python tools/coresidency_repro.py 2,1 300 gemm640
+  ;;
+s2)  # C = 1 (no hand-offs at all): baseline alone, rate beside the GEMM, and the audit build (tools: gam_decode_cluster.h GAM_RC_AUDIT)
+  repro c1none   libgigaam_hip.so       GAM_RNNT_EXCLUSIVE=0 timeout 300 python tools/coresidency_repro.py 1 2000 none
+  repro c1gemm   libgigaam_hip.so       GAM_RNNT_EXCLUSIVE=0 timeout 300 python tools/coresidency_repro.py 1 3000 gemm640
+  repro c1audit  libgigaam_hip_audit.so GAM_RNNT_EXCLUSIVE=0 timeout 600 python tools/coresidency_repro.py 1 3000 gemm640
+  repro c2audit  libgigaam_hip_audit.so GAM_RNNT_EXCLUSIVE=0 timeout 600 python tools/coresidency_repro.py 2 1500 gemm640
+  repro c1legacy libgigaam_hip.so       GAM_RNNT_EXCLUSIVE=0 GAM_SP_MIN_M=1073741824 timeout 300 python tools/coresidency_repro.py 1 3000 legacy
+  repro c1attn   libgigaam_hip.so       GAM_RNNT_EXCLUSIVE=0 timeout 300 python tools/coresidency_repro.py 1 2000 attention
+  repro c1auditn libgigaam_hip_audit.so GAM_RNNT_EXCLUSIVE=0 timeout 600 python tools/coresidency_repro.py 1 1000 none
+  grep -a "gam-audit\|MISMATCH" $OUT/c1audit.err | head -150 > $OUT/c1audit_head.txt
+  grep -a "gam-audit\|MISMATCH" $OUT/c2audit.err | head -80 > $OUT/c2audit_head.txt
+  grep -a "gam-audit\] total\|gam-audit\] decode" $OUT/*.err | awk '{print $1, $2, $3, $4, $5, $6, $7, $8, $9, $10, $11, $12}' | sort | uniq -c | sort -rn | head -40 > $OUT/audit_summary.txt
+  tail -5 $OUT/c1audit_head.txt; cat $OUT/audit_summary.txt | head -20
+  ;;
+s3)  # v_pk_fma_f32 low half: canary + the decode without hipcc's packed FMAs (-fno-slp-vectorize)
+  timeout 900 python tools/pkfma_canary.py 4 2> $OUT/pkfma.err | tee $OUT/pkfma.txt
+  repro c1noslp   libgigaam_hip_noslp.so       GAM_RNNT_EXCLUSIVE=0 timeout 300 python tools/coresidency_repro.py 1 3000 gemm640
+  repro c1base    libgigaam_hip.so             GAM_RNNT_EXCLUSIVE=0 timeout 300 python tools/coresidency_repro.py 1 3000 gemm640
+  repro c1audns   libgigaam_hip_audit_noslp.so GAM_RNNT_EXCLUSIVE=0 timeout 600 python tools/coresidency_repro.py 1 1500 gemm640
+  repro c2audns   libgigaam_hip_audit_noslp.so GAM_RNNT_EXCLUSIVE=0 timeout 600 python tools/coresidency_repro.py 2 1000 gemm640
+  repro c1noslp2  libgigaam_hip_noslp.so       GAM_RNNT_EXCLUSIVE=0 timeout 300 python tools/coresidency_repro.py 1,2,3,4 2000 gemm640
+  grep -a "gam-audit\] total" $OUT/*.err | tee $OUT/audit_totals.txt
+  grep -a "gam-audit\]   site" $OUT/c1audns.err | head -40 > $OUT/c1audns_head.txt
+  ;;
+s4)  timeout 900 python tools/pkfma_canary.py 4 2> $OUT/pkfma.err | tee $OUT/pkfma.txt; tail -3 $OUT/pkfma.err ;;
+s5)  timeout 900 python tools/pkfma_rule.py 3 2> $OUT/rule.err | tee $OUT/rule.txt; tail -3 $OUT/rule.err ;;
+*) echo "unknown stage $STAGE"; exit 2;;
+esac
