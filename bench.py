@@ -261,7 +261,44 @@ def _ref_margin_of(model, is_rnnt, enc, elen, i):
     return min(rec) if rec else None
 
 
-def cpu_baseline(ckpt, batches, gpu_decoded, sweep: bool, equal_lengths: bool, port_too: bool):
+def _ref_logprobs_of(model, is_rnnt, enc, elen, i):
+    """The REFERENCE's log-probs for utterance i: CTC [n, V] per frame; RNN-T [steps, V], one row per joint evaluation in the order its
+    greedy loop makes them (gigaam/decoding.py:162-205 through a recorder on RNNTJoint.joint)."""
+    n = int(elen[i])
+    e1 = enc[i:i + 1, :, :n].contiguous()
+    if not is_rnnt:
+        return model.head(e1)[0, :n].clone()
+    rec, orig = [], model.head.joint.joint
+
+    def spy(f, g):
+        out = orig(f, g)
+        rec.append(out.reshape(-1, out.shape[-1])[0].clone())
+        return out
+    model.head.joint.joint = spy
+    try:
+        model.decoding.decode(model.head, e1, elen[i:i + 1])
+    finally:
+        del model.head.joint.joint
+    return torch.stack(rec) if rec else torch.zeros((0, 1))
+
+
+def _mismatch_report(ref_lp, gpu_lp):
+    """Walk the two log-prob sequences (frames for CTC, joint evaluations for RNN-T: identical steps until the first differing
+    decision) up to AND INCLUDING the first step whose argmax differs: the largest |GPU - reference| over those rows, and the
+    reference's own top-1 / top-2 margin on the diverging row -- a near-tie inside the 1e-3 logit bar, or a real disagreement."""
+    n = min(int(ref_lp.shape[0]), int(gpu_lp.shape[0]))
+    if n == 0:
+        return {"steps_compared": 0}
+    a, b = ref_lp[:n].float(), gpu_lp[:n].float()
+    diff = (a - b).abs().amax(dim=1)
+    am = a.argmax(dim=1) != b.argmax(dim=1)
+    first = int(am.nonzero()[0]) if bool(am.any()) else n - 1
+    t2 = a[first].topk(2).values
+    return {"first_differing_step": first if bool(am.any()) else None, "steps_compared": first + 1,
+            "max_logit_diff": float(diff[:first + 1].max()), "reference_margin_at_that_step": float(t2[0] - t2[1])}
+
+
+def cpu_baseline(ckpt, batches, gpu_decoded, sweep: bool, equal_lengths: bool, port_too: bool, gpu_probe=None, ref_ids_out=None):
     """The reference's OWN modules (oracle/_ref: CPython bytecode of /root/reference/gigaam/*.py made by oracle/build_ref.py,
     imported through oracle/ref_shim.py) on this box's host cores, fp32: ``GigaAM.forward`` (FeatureExtractor ->
     ConformerEncoder, gigaam/model.py:27-37) + ``decoding.decode(head, ...)`` (model.py:96-124) = the body of
@@ -318,6 +355,8 @@ def cpu_baseline(ckpt, batches, gpu_decoded, sweep: bool, equal_lengths: bool, p
     dt = time.perf_counter() - t0
     dec = [d for o in outs for d in o[0]]
     same = [a == (list(b[0]), list(b[1])) for a, b in zip(dec, gpu_decoded[:n_utts])]
+    if ref_ids_out is not None:
+        ref_ids_out.update({i: d for i, d in enumerate(dec)})
     out = {
         "value": round(audio_s / dt, 3), "unit": "audio-sec/wall-sec", "cores": best, "host_cpus": ncpu,
         "kind": "reference" if use_ref else "port",
@@ -346,6 +385,19 @@ def cpu_baseline(ckpt, batches, gpu_decoded, sweep: bool, equal_lengths: bool, p
             with torch.inference_mode():
                 out["mismatch_reference_min_margin"] = {str(i): _ref_margin_of(model, is_rnnt, outs[rows[i][0]][1], outs[rows[i][0]][2], rows[i][1])
                                                         for i in bad[:8]}
+                if gpu_probe is not None:
+                    # for every utterance whose ids differ, the logit difference GPU vs reference up to the diverging
+                    # decision (north_star: RNN-T logits within 1e-3), and the same utterance decoded at the serial path's cluster size
+                    rep, worst = {}, 0.0
+                    for i in bad[:8]:
+                        ref_lp = _ref_logprobs_of(model, is_rnnt, outs[rows[i][0]][1], outs[rows[i][0]][2], rows[i][1])
+                        gpu_lp, extra = gpu_probe(i)
+                        r = _mismatch_report(ref_lp, gpu_lp)
+                        r.update(extra)
+                        rep[str(i)] = r
+                        worst = max(worst, r.get("max_logit_diff", 0.0))
+                    out["mismatch_logits"] = rep
+                    out["mismatch_max_logit_diff"] = worst
     if use_ref and port_too:
         t0 = time.perf_counter()
         pdec = [d for w, l in calls for d in run_port(w, l)[0]]
@@ -997,8 +1049,37 @@ def main():
                 gpu_dec = [(out[g][0], out[g][1]) for g in sel]
             else:
                 gpu_dec = [tuple(last5["res"][g]) for g in sel]
+            def gpu_probe(i):
+                """(GPU log-probs of utterance i of the CPU sample -- per frame for CTC, per joint evaluation for RNN-T, decoded in its own
+                batch exactly as the timed step decoded it, same cluster size --, extra fields for the report)."""
+                from gigaam_amd.engine import HipEngine
+                bi, r = 0, i
+                while r >= int(keep[bi][0].shape[0]):
+                    r -= int(keep[bi][0].shape[0])
+                    bi += 1
+                w_d, l_d = keep[bi][0].to(dev), keep[bi][1].to(dev)
+                enc_d, elen_d = eng.encode(*eng.frontend(w_d, l_d))
+                if not is_rnnt:
+                    return eng.ctc_head(enc_d)[r, :int(elen_d[r])].cpu(), {}
+                b_, tp_ = int(enc_d.shape[0]), int(enc_d.shape[2])
+                cap = tp_ + max(len(g[0]) for g in gpu_dec) + 16
+                c_timed = (HipEngine.side_cluster(b_, args.rnnt_side_cus if args.rnnt_side_cus > 0 else (96 if eng.cfg.num_classes <= 64 else 160))
+                           if (rnnt_overlap and cfgno != 1) else -1)
+                eng.set_rnnt_cluster(c_timed)
+                try:
+                    d = eng.rnnt_greedy(enc_d, elen_d, max_sym, dump_cap=cap)
+                    ids_t = HipEngine.collect(d)[0][r]
+                    lp = d[3][r, :int(d[4][r])].cpu()
+                finally:
+                    eng.set_rnnt_cluster(-1)
+                ids_full = HipEngine.collect(eng.rnnt_greedy(enc_d, elen_d, max_sym))[0][r]
+                want = cpu_ids_of.get(i)
+                return lp, {"cluster_size_timed": c_timed, "ids_identical_at_full_cluster_size": (None if want is None else bool(list(ids_full[0]) == want[0] and list(ids_full[1]) == want[1])),
+                            "timed_ids_reproduced_by_probe": bool((list(ids_t[0]), list(ids_t[1])) == (list(gpu_dec[i][0]), list(gpu_dec[i][1])))}
+            cpu_ids_of = {}
             line["cpu_baseline"] = cpu_baseline(ckpt, keep, gpu_dec, sweep=(cfgno == 2), equal_lengths=cfgno in (1, 2, 3) and not args.ragged,
-                                                port_too=(cfgno == 2 and not args.no_port_leg))
+                                                port_too=(cfgno == 2 and not args.no_port_leg), gpu_probe=gpu_probe if cfgno in (1, 2, 3, 4) else None,
+                                                ref_ids_out=cpu_ids_of)
         except Exception as e:  # the bench line must still print
             import traceback
             line["cpu_baseline"] = {"error": repr(e), "traceback": traceback.format_exc()[-600:]}

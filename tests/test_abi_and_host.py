@@ -1,6 +1,7 @@
 """CPU: the C-ABI library loads and exports every declared symbol; host-side logic."""
 import os
 import re
+import sys
 import wave
 
 import numpy as np
@@ -365,3 +366,21 @@ def test_side_cluster_sizes():
     from gigaam_amd.engine import HipEngine
     assert [HipEngine.side_cluster(b, 96) for b in (1, 8, 9, 16, 32, 33, 64, 200)] == [8, 8, 6, 6, 3, 2, 1, 1]
     assert HipEngine.side_cluster(32, 160) == 5 and HipEngine.side_cluster(32, 32) == 1 and HipEngine.side_cluster(33, 8) == 1
+
+
+def test_bench_mismatch_report_walks_to_the_first_differing_decision():
+    """bench.py's cpu_baseline leg: for an utterance whose ids differ from the reference's, the report is the largest logit difference up to
+    and including the first step whose argmax differs, and the reference's margin there (VERDICT r5 #2)."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    ref = torch.tensor([[0.0, -1.0, -2.0], [-0.5, -0.50001, -3.0], [-9.0, 0.0, -9.0]])
+    gpu = ref.clone()
+    gpu[0, 2] += 4e-4                      # inside the bar, same decision
+    gpu[1, 1] += 3e-5                      # flips a near-tie
+    gpu[2, 0] += 5.0                       # behind the divergence: must not count
+    r = bench._mismatch_report(ref, gpu)
+    assert r["first_differing_step"] == 1 and r["steps_compared"] == 2
+    assert abs(r["max_logit_diff"] - 4e-4) < 1e-6 and abs(r["reference_margin_at_that_step"] - 1e-5) < 2e-6
+    same = bench._mismatch_report(ref, ref.clone())
+    assert same["first_differing_step"] is None and same["max_logit_diff"] == 0.0

@@ -46,5 +46,18 @@ s3)  # v_pk_fma_f32 low half: canary + the decode without hipcc's packed FMAs (-
   ;;
 s4)  timeout 900 python tools/pkfma_canary.py 4 2> $OUT/pkfma.err | tee $OUT/pkfma.txt; tail -3 $OUT/pkfma.err ;;
 s5)  timeout 900 python tools/pkfma_rule.py 3 2> $OUT/rule.err | tee $OUT/rule.txt; tail -3 $OUT/rule.err ;;
+s6)  # mid-round check: GPU tests, smoke, the driver's bench command, config 3 / 4 with and without the whole-CU claim
+  export GAM_TEST_REPORT=$OUT/measured_errors.jsonl; rm -f $GAM_TEST_REPORT
+  ( time timeout 1500 python -m pytest tests -q -m gpu -x ) > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -5 $OUT/pytest_gpu.log
+  ( timeout 300 python __graft_entry__.py --smoke ) > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $OUT/smoke.log
+  ( timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 ) > $OUT/bench.log 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 600 $OUT/bench.log
+  for ex in 1 0 1 0; do
+    for c in 3 4; do
+      ( GAM_RNNT_EXCLUSIVE=$ex timeout 400 python bench.py --config $c --cpu-utts 0 --steps 8 --warmup 2 --no-profile --no-power ) 2>> $OUT/excl.err | grep -a '^{' | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('config $c exclusive $ex:', d['ms_per_step'], 'ms', d['value'], 'x')" | tee -a $OUT/excl.txt
+    done
+  done
+  ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
