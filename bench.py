@@ -510,6 +510,7 @@ def main():
     ap.add_argument("--model", default=None, help="override the configuration's model")
     ap.add_argument("--batch", type=int, default=32, help="configs 2/3: utterances per GPU (weak) or in total (strong)")
     ap.add_argument("--seconds", type=float, default=20.0)
+    ap.add_argument("--no-pack", action="store_true", help="A/B: ragged batches keep the padded row layout (no host lengths handed to the encoder)")
     ap.add_argument("--ragged", action="store_true", help="configs 2/3: utterance lengths linspace(seconds/2, seconds, batch) instead of equal "
                     "(SURVEY 8d's second run); the CPU reference leg then decodes the batch whole")
     ap.add_argument("--utts-per-gpu", type=int, default=128, help="config 4, weak scaling")
@@ -595,11 +596,22 @@ def main():
 
     rnnt_overlap = is_rnnt and args.rnnt_overlap != 0
 
-    def decode_dev(wav, wlen, overlap=False):
+    host_lens = {}      # id(device length tensor) -> (the tensor, its feature lengths as host integers): what the caller of a real
+                        # transcribe() has anyway (file lengths) -- a ragged batch then runs on its valid frames only (engine.encode)
+
+    def note_host(wlen_dev, samples):
+        if not args.no_pack:
+            host_lens[id(wlen_dev)] = (wlen_dev, eng.host_feat_lengths(samples))
+
+    def decode_dev(wav, wlen, overlap=False, host=None):
         """frontend + encoder + greedy decode, launched, no host sync.  ``overlap`` (RNN-T, another batch follows before this one is
-        collected): the decode goes to the engine's side stream with small clusters, beside the next batch's encoder."""
+        collected): the decode goes to the engine's side stream with small clusters, beside the next batch's encoder.  ``host``: the
+        batch's sample counts on the host (else what note_host registered for this length tensor)."""
         feat, flen = eng.frontend(wav, wlen)
-        enc, elen = eng.encode(feat, flen)
+        hfl = None
+        if not args.no_pack:
+            hfl = eng.host_feat_lengths(host) if host is not None else host_lens.get(id(wlen), (None, None))[1]
+        enc, elen = eng.encode(feat, flen, host_lengths=hfl)
         if is_rnnt:
             return eng.rnnt_greedy(enc, elen, max_sym, overlap=overlap and rnnt_overlap, side_cus=args.rnnt_side_cus)
         return eng.ctc_greedy(enc, elen)
@@ -625,6 +637,7 @@ def main():
             mine_l = ragged_global[g0:g1] or [int(seconds * 16000)]
             wav_h, wlen_h = synth.synth_audio(len(mine_l), seconds, seed=1000, index0=g0, lengths=mine_l)
         wav, wlen = wav_h.to(dev), wlen_h.to(dev)          # resident in HBM before the timed region
+        note_host(wlen, wlen_h)
         rows = max(shard_range(n_global, r, n_ranks)[1] - shard_range(n_global, r, n_ranks)[0] for r in range(n_ranks))
         audio_s = seconds * n_global if ragged_global is None else sum(ragged_global) / 16000.0
         idx_dev = torch.full((rows,), -1, dtype=torch.int32, device=dev)
@@ -675,6 +688,9 @@ def main():
         mine = shard.deal((n_utts + 31) // 32, rank, n_ranks)
         host_batches = workloads.config4_batches(n_utts, 32, only_batches=set(range((n_utts + 31) // 32)) if n_ranks == 1 else None)
         batches = [(w.to(dev) if j in mine else w, l.to(dev) if j in mine else l, g) for j, (w, l, g) in enumerate(host_batches)]
+        for j, (_, l_h, _) in enumerate(host_batches):
+            if j in mine:
+                note_host(batches[j][1], l_h)
         audio_s = float(sum(int(l.sum()) for _, l, _ in host_batches)) / 16000.0
         cap = eng.enc_frames(eng.feat_frames(20 * 16000)) * max_sym
         tok = model.decoding.tokenizer
@@ -729,7 +745,7 @@ def main():
             t_s, marks = time.perf_counter(), []
             for wav_b, len_b in feeder:                                       # pinned, double-buffered H2D
                 t_a = time.perf_counter()
-                out_b = decode_dev(wav_b, len_b)                              # launched; collected one batch later
+                out_b = decode_dev(wav_b, len_b, host=feeder.host_lengths)    # launched; collected one batch later
                 t_b = time.perf_counter()
                 if pending is not None:
                     rows += [(my_idx[len(rows) + k], i, f) for k, (i, f) in enumerate(ragged_host(pending))]
@@ -828,7 +844,7 @@ def main():
         def run_feeder(fd):
             pending, n_done = None, 0
             for wb, lb in fd:
-                out_b = decode_dev(wb, lb)
+                out_b = decode_dev(wb, lb, host=fd.host_lengths)
                 if pending is not None:
                     ragged_host(pending); n_done += 1
                 pending = out_b

@@ -26,6 +26,7 @@
 #include "gam_gemm16.h"
 #include "gam_gemm_sp.h"
 #include "gam_norm.h"
+#include "gam_pack.h"
 #include "gam_stem.h"
 
 namespace {
@@ -109,7 +110,9 @@ struct gam_handle {
   int rnnt_cluster = -1;        // GAM_RNNT_CLUSTER: 0 = one workgroup per utterance, N = force N per utterance, -1 = auto
   int rnnt_coop = 1;            // GAM_RNNT_COOP=0: plain instead of cooperative launch of the cluster kernel
   int rnnt_force_timeout = 0;   // GAM_RNNT_FORCE_TIMEOUT=1 (test hook): odd utterances' clusters report a failed hand-off
-  int rnnt_exclusive = 1;       // GAM_RNNT_EXCLUSIVE=0: decode workgroups ask for their own LDS size only (default: the CU's whole LDS)
+  int rnnt_exclusive = 0;       // GAM_RNNT_EXCLUSIVE=1: decode workgroups ask for their CU's whole LDS, so nothing that uses LDS is placed beside them
+                                // (r05's protection; not needed since r06 removed the packed-fp32 instructions that a neighbour's MFMAs disturbed --
+                                // tests/test_hip_hardening.py runs the decode beside another stream's GEMM both ways)
   DevBuf rnnt_x;                // hand-off granules + status word of the cluster kernel
   DevBuf rnnt_audit;            // -DGAM_RC_AUDIT=1 diagnosis builds: the cluster kernel's audit log
   bool audit_pending = false; int audit_last_c = 0; long audit_decodes = 0, audit_hit_decodes = 0;
@@ -129,6 +132,8 @@ struct gam_handle {
   DevBuf dec_splitk_ws;                 // split-K partial sums of the DECODE class's GEMMs: a decode may run on a side stream beside
                                         // the next batch's encoder (r05), so it shares no scratch with it (tok / logits / encp / rnnt_x
                                         // are the decode's alone already)
+  DevBuf pack_idx;      // packed rows (gam_pack.h): cu [B + 1] | row_t [rows] | row_src [rows], as ints
+  int use_pack = 1;     // GAM_PACK=0: ragged batches keep the padded row layout even when the caller gave host lengths (A/B switch)
   int use_splitk = 1;   // GAM_SPLITK=0 disables split-K for small grids
   int fuse_reduce = 1;  // GAM_FUSE_REDUCE=0: the split-K reduce of a residual GEMM stays a kernel of its own (A/B switch)
   // hipGraph replay of the Conformer-layer launch sequence for small batches (launch-bound: a 5 s clip is
@@ -502,6 +507,7 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   if (const char* e = getenv("GAM_SP")) h->use_sp = atoi(e);
   if (const char* e = getenv("GAM_SP_MIN_M")) h->sp_min_m = atoi(e);
   if (const char* e = getenv("GAM_SPLITK")) h->use_splitk = atoi(e);
+  if (const char* e = getenv("GAM_PACK")) h->use_pack = atoi(e);
   if (const char* e = getenv("GAM_FUSE_REDUCE")) h->fuse_reduce = atoi(e);
   if (const char* e = getenv("GAM_GRAPH")) h->use_graph = atoi(e);
   if (const char* e = getenv("GAM_GRAPH_MAX_ROWS")) h->graph_max_rows = atoi(e);
@@ -547,7 +553,7 @@ void gam_destroy(gam_handle* h) {
 #endif
   for (void* p : h->owned) hipFree(p);
   DevBuf* bufs[] = {&h->wavp, &h->spec, &h->img, &h->c2, &h->xin, &h->y1, &h->x, &h->y, &h->yr, &h->hbuf,
-                    &h->qkv, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes, &h->op_sp, &h->splitk_ws, &h->dec_splitk_ws, &h->rsbuf, &h->op_rs, &h->rnnt_x, &h->rnnt_audit, &h->jz, &h->jp, &h->jl};
+                    &h->qkv, &h->ctx, &h->ubuf, &h->zbuf, &h->tok, &h->logits, &h->encp, &h->pbuf, &h->aplanes, &h->op_planes, &h->op_sp, &h->splitk_ws, &h->dec_splitk_ws, &h->rsbuf, &h->op_rs, &h->rnnt_x, &h->rnnt_audit, &h->jz, &h->jp, &h->jl, &h->pack_idx};
   for (DevBuf* b : bufs)
     if (b->p) hipFree(b->p);
   if (h->lens) hipFree(h->lens);
@@ -989,7 +995,7 @@ int gam_frontend(gam_handle* h, const float* wav, const int64_t* wav_len, int B,
 
 // -----------------------------------------------------------------------------------
 static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len, int B, int64_t T, float* encoded,
-                       int32_t* enc_len, int n_layers_run, float* tokens_out, hipStream_t s) {
+                       int32_t* enc_len, int n_layers_run, float* tokens_out, hipStream_t s, const int64_t* feat_len_host = nullptr) {
   if (!h || !h->finalized) return fail(h, -1, "gam_encode before gam_finalize");
   if (!h->has_encoder) return fail(h, -1, "this handle was finalized without encoder weights");
   const gam_config& c = h->cfg;
@@ -1005,6 +1011,22 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
   // conv1d: stage-1 output rows per utterance = 2*Ta >= T1 + 4.
   int Ta = conv2d ? std::max(Tv + 1, (T1 + 3) / 2) : std::max(Tv, (T1 + 5) / 2);
   const int N = B * Ta;
+  // Packed rows (gam_pack.h): with the lengths known on the HOST (gam_encode_varlen) a ragged batch runs its layers on the valid frames
+  // only -- NR rows instead of N, utterance b at rows cu[b] .. -- when that drops at least 3 % of the rows.  Equal-length batches, single
+  // utterances and callers without host lengths keep the padded layout (and its results, bit for bit).
+  bool packed = false;
+  int NR = N, Tmax = Ta;
+  if (feat_len_host != nullptr && h->use_pack && B > 1 && B <= 1024) {
+    long long sum = 0;
+    int mx = 0;
+    for (int b = 0; b < B; ++b) {
+      const int64_t l = std::min<int64_t>(std::max<int64_t>(feat_len_host[b], 0), T);
+      const int l2 = (int)half_up(half_up(l));      // = len2 of gam_lengths_kernel
+      sum += l2;
+      mx = std::max(mx, l2);
+    }
+    if (sum > 0 && sum * 100 <= (long long)N * 97) { packed = true; NR = (int)sum; Tmax = mx; }
+  }
 
   if (B > h->lens_cap) {
     if (h->lens) HIPCHK(h, hipFree(h->lens));
@@ -1023,12 +1045,21 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
   if (int r = ensure(h, h->ubuf, (size_t)N * 2 * D)) return r;
   if (int r = ensure(h, h->zbuf, (size_t)N * D)) return r;
   if (int r = ensure(h, h->rsbuf, (size_t)N + 64)) return r;
+  if (packed)
+    if (int r = ensure(h, h->pack_idx, (size_t)1032 + 2 * (size_t)N)) return r;
+  int* const cu = packed ? reinterpret_cast<int*>(h->pack_idx.p) : nullptr;
+  int* const row_t = packed ? cu + 1032 : nullptr;
+  int* const row_src = packed ? row_t + N : nullptr;
 
   {
     ProfScope ps(h, s, GAM_PF_MISC, 0.0);
     hipLaunchKernelGGL(gam_lengths_kernel, dim3(gam_cdiv(B, 64)), dim3(64), 0, s, (const long long*)feat_len, B, (int)T, 2,
                        len0, len1, len2, elen);
     HIPCHK(h, hipGetLastError());
+    if (packed) {
+      hipLaunchKernelGGL(gam_pack_index_kernel, dim3(1), dim3(256), 0, s, len2, B, Ta, NR, cu, row_t, row_src, h->range_flag);
+      HIPCHK(h, hipGetLastError());
+    }
   }
 
   // Large batches: every big GEMM runs on the LDS-DMA kernel of gam_gemm_sp.h, and the kernels that
@@ -1068,10 +1099,11 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     GamGemmArgs g = gemm_args(h->img.p, 0, h->c2_w, h->c2_b, h->c2.p, C, N * F2, C, 9 * C);
     g.a_mode = 1; g.conv_fp = FP; g.conv_c = C; g.conv_f2 = F2;
     g.lens = len2; g.rpb = Ta * F2; g.fdiv = F2;
+    g.skip_pad = packed ? 1 : 0;      // 16-frame row tiles behind an utterance's last frame: 12 rounds of tiles shrink with the batch's padding
     if (sp && C % 32 == 0) { sp_a(g); g.c_split = spf; }
     g.c_guard = 1;
     if (int r = gemm(h, s, g, GAM_ACT_RELU, GAM_PF_CONV2, &h->s_c2)) return r;
-    GamGemmArgs l = gemm_args(h->c2.p, (long)F2 * C, h->lin_w, h->lin_b, h->x.p, D, N, D, F2 * C);
+    GamGemmArgs l = gemm_args(h->c2.p, (long)F2 * C, h->lin_w, h->lin_b, packed ? h->y.p : h->x.p, D, N, D, F2 * C);
     if (sp && C % 32 == 0) sp_a(l);
     if (int r = gemm(h, s, l, GAM_ACT_NONE, GAM_PF_GEMM, &h->s_lin)) return r;
   } else {
@@ -1092,9 +1124,14 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     g1.lens = len1; g1.rpb = T1a; g1.fdiv = 1;
     g1.remap = 1; g1.out_rpb = 2 * Ta; g1.out_shift = pad; g1.rows_valid = std::min(T1a, 2 * Ta - pad);
     if (int r = gemm(h, s, g1, GAM_ACT_RELU, GAM_PF_CONV2, &h->s_c1)) return r;
-    GamGemmArgs g2 = gemm_args(h->y1.p, 2L * C, h->c2_w, h->c2_b, h->x.p, D, N, D, ks * C);
+    GamGemmArgs g2 = gemm_args(h->y1.p, 2L * C, h->c2_w, h->c2_b, packed ? h->y.p : h->x.p, D, N, D, ks * C);
     g2.lens = len2; g2.rpb = Ta; g2.fdiv = 1;
     if (int r = gemm(h, s, g2, GAM_ACT_RELU, GAM_PF_CONV2, &h->s_c2)) return r;
+  }
+  if (packed) {   // the stem's padded rows -> packed rows (the only copy the layout costs: 2 x NR x D x 4 bytes)
+    ProfScope ps(h, s, GAM_PF_STEM, (double)NR * D * 8.0);
+    hipLaunchKernelGGL(gam_gather_rows_kernel, dim3(std::min(4096, gam_cdiv(NR * (D / 4), 256))), dim3(256), 0, s, h->y.p, row_src, h->x.p, NR, D);
+    HIPCHK(h, hipGetLastError());
   }
 
   // ------------------------------ Conformer layers ------------------------------
@@ -1107,7 +1144,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
   hipStream_t s = ls;   // (shadows the caller's stream: the capture runs on a private one)
   GamLnArgs ln;
   memset(&ln, 0, sizeof ln);
-  ln.rows = N; ln.d = D; ln.ta = Ta; ln.dk = dk; ln.eps = 1e-5f; ln.rcos = h->rot_cos; ln.rsin = h->rot_sin;
+  ln.rows = NR; ln.d = D; ln.ta = Ta; ln.row_t = row_t; ln.dk = dk; ln.eps = 1e-5f; ln.rcos = h->rot_cos; ln.rsin = h->rot_sin;
   ln.rope_rows = c.pos_emb_max_len;
   // split-fp16 modes: every LayerNorm hands its GEMMs a per-row power-of-two scale (gam_row_scale)
   float* const rs = split_mode(h) && h->use_rowscale ? h->rsbuf.p : nullptr;
@@ -1123,10 +1160,10 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     const LayerW& L = h->layers[li];
     // --- FFN 1 (macaron half step) ---
     {
-      GamGemmArgs g = gemm_args(h->y.p, D, L.ff1_w1, L.ff1_b1, h->hbuf.p, DFF, N, DFF, D);
+      GamGemmArgs g = gemm_args(h->y.p, D, L.ff1_w1, L.ff1_b1, h->hbuf.p, DFF, NR, DFF, D);
       sp_a(g); g.c_split = spf; g.a_rs = rs; g.c_guard = 1;
       if (int r = gemm(h, s, g, GAM_ACT_SILU, GAM_PF_GEMM, &L.s_ff1_w1)) return r;
-      GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff1_w2, L.ff1_b2, h->x.p, D, N, D, DFF);
+      GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff1_w2, L.ff1_b2, h->x.p, D, NR, D, DFF);
       g2.R = h->x.p; g2.ldr = D; g2.alpha = 0.5f;
       sp_a(g2);
       if (int r = gemm(h, s, g2, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_ff1_w2, &pend)) return r;
@@ -1141,19 +1178,19 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       // q, k and v are split to fp16 unscaled by the attention kernel: range guard on all of them.
       const bool one_launch = rel || (sp && (2 * D) % 256 == 0);   // (the operand switch sits on a tile boundary of either tile width)
       if (one_launch) {
-        GamGemmArgs gq = gemm_args(rel ? h->y.p : h->yr.p, D, L.wqkv, L.bqkv, h->qkv.p, 3 * D, N, 3 * D, D);
+        GamGemmArgs gq = gemm_args(rel ? h->y.p : h->yr.p, D, L.wqkv, L.bqkv, h->qkv.p, 3 * D, NR, 3 * D, D);
         sp_a(gq); gq.a_rs = rs; gq.c_guard = 1;
         if (!rel) { gq.Asp2 = reinterpret_cast<const _Float16*>(h->y.p); gq.n_switch = 2 * D; }
         if (int r = gemm(h, s, gq, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wqkv)) return r;
       } else {
-        GamGemmArgs gq = gemm_args(h->yr.p, D, L.wqkv, L.bqkv, h->qkv.p, 3 * D, N, 2 * D, D);
+        GamGemmArgs gq = gemm_args(h->yr.p, D, L.wqkv, L.bqkv, h->qkv.p, 3 * D, NR, 2 * D, D);
         sp_a(gq); gq.a_rs = rs; gq.c_guard = 1;
         if (int r = gemm(h, s, gq, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wqkv)) return r;
         W16 wv16 = L.s_wqkv;   // rows 2D .. 3D of the same planes
         const size_t off = (size_t)2 * D * D;
         if (wv16.hi) { wv16.hi += off; wv16.lo += off; }
         if (wv16.sp) wv16.sp += 2 * off;
-        GamGemmArgs gv = gemm_args(h->y.p, D, L.wqkv + off, L.bqkv + 2 * D, h->qkv.p + 2 * D, 3 * D, N, D, D);
+        GamGemmArgs gv = gemm_args(h->y.p, D, L.wqkv + off, L.bqkv + 2 * D, h->qkv.p + 2 * D, 3 * D, NR, D, D);
         sp_a(gv); gv.a_rs = rs; gv.c_guard = 1;
         if (int r = gemm(h, s, gv, GAM_ACT_NONE, GAM_PF_GEMM, &wv16)) return r;
       }
@@ -1166,7 +1203,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       memset(&at, 0, sizeof at);
       at.q = h->qkv.p; at.k = h->qkv.p + D; at.v = h->qkv.p + 2 * D; at.ctx = h->ctx.p; at.ctx_split = spf;
       at.lens = B > 1 ? len2 : nullptr;  // encoder.py:620-624: no mask at batch 1
-      at.B = B; at.Ta = Ta; at.Tv = Tv; at.H = H; at.ldq = 3 * D; at.ldv = 3 * D; at.ldo = D;
+      at.cu = cu; at.B = B; at.Ta = packed ? Tmax : Ta; at.Tv = Tv; at.H = H; at.ldq = 3 * D; at.ldv = 3 * D; at.ldo = D;
       at.scale = 1.0f / sqrtf((float)dk);
       at.pbuf = rel ? h->pbuf.p : nullptr; at.pos_u = L.pos_u; at.pos_v = L.pos_v; at.ldp = D;
       {
@@ -1174,7 +1211,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
         hipError_t e = gam_launch_attn_mode(at, dk, split_mode(h), s, h->gemm_mode == GAM_GEMM_F16 ? 1 : 3, h->ncu);
         if (e != hipSuccess) return fail(h, -2, "attention launch: %s", hipGetErrorString(e));
       }
-      GamGemmArgs go = gemm_args(h->ctx.p, D, L.wo, L.bo, h->x.p, D, N, D, D);
+      GamGemmArgs go = gemm_args(h->ctx.p, D, L.wo, L.bo, h->x.p, D, NR, D, D);
       go.R = h->x.p; go.ldr = D;
       sp_a(go);
       if (int r = gemm(h, s, go, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_wo, &pend)) return r;
@@ -1185,19 +1222,19 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       a.x = h->x.p; a.out1 = h->y.p; a.w1 = L.ln_conv_w; a.b1 = L.ln_conv_b;
       a.split1 = spf;
       if (int r = layernorm(h, s, a, 0, &pend)) return r;
-      GamGemmArgs g1 = gemm_args(h->y.p, D, L.pw1_w, L.pw1_b, h->ubuf.p, 2 * D, N, 2 * D, D);
+      GamGemmArgs g1 = gemm_args(h->y.p, D, L.pw1_w, L.pw1_b, h->ubuf.p, 2 * D, NR, 2 * D, D);
       sp_a(g1); g1.a_rs = rs;
       if (int r = gemm(h, s, g1, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_pw1)) return r;
       GamConvModArgs cm;
       cm.u = h->ubuf.p; cm.z = h->zbuf.p; cm.dw_w = L.dw_w; cm.dw_b = L.dw_b; cm.n_scale = L.cn_scale; cm.n_shift = L.cn_shift;
-      cm.lens = len2; cm.B = B; cm.Ta = Ta; cm.Tv = Tv; cm.d = D; cm.ks = c.conv_kernel_size; cm.eps = 1e-5f;
+      cm.lens = len2; cm.cu = cu; cm.B = B; cm.Ta = packed ? Tmax : Ta; cm.Tv = Tv; cm.d = D; cm.ks = c.conv_kernel_size; cm.eps = 1e-5f;
       cm.z_split = spf; cm.range_flag = h->use_range ? h->range_flag : nullptr;
       {
-        ProfScope ps(h, s, GAM_PF_CONVMOD, (double)N * D * 3 * 4.0);
+        ProfScope ps(h, s, GAM_PF_CONVMOD, (double)NR * D * 3 * 4.0);
         hipError_t e = gam_launch_convmod(cm, c.conv_norm_type == GAM_NORM_LAYER, s);
         if (e != hipSuccess) return fail(h, -2, "conv-module launch (k=%d): %s", cm.ks, hipGetErrorString(e));
       }
-      GamGemmArgs g2 = gemm_args(h->zbuf.p, D, L.pw2_w, L.pw2_b, h->x.p, D, N, D, D);
+      GamGemmArgs g2 = gemm_args(h->zbuf.p, D, L.pw2_w, L.pw2_b, h->x.p, D, NR, D, D);
       g2.R = h->x.p; g2.ldr = D;
       sp_a(g2);
       if (int r = gemm(h, s, g2, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_pw2, &pend)) return r;
@@ -1208,10 +1245,10 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
       a.x = h->x.p; a.out1 = h->y.p; a.w1 = L.ln_ff2_w; a.b1 = L.ln_ff2_b;
       a.split1 = spf;
       if (int r = layernorm(h, s, a, 0, &pend)) return r;
-      GamGemmArgs g = gemm_args(h->y.p, D, L.ff2_w1, L.ff2_b1, h->hbuf.p, DFF, N, DFF, D);
+      GamGemmArgs g = gemm_args(h->y.p, D, L.ff2_w1, L.ff2_b1, h->hbuf.p, DFF, NR, DFF, D);
       sp_a(g); g.c_split = spf; g.a_rs = rs; g.c_guard = 1;
       if (int r = gemm(h, s, g, GAM_ACT_SILU, GAM_PF_GEMM, &L.s_ff2_w1)) return r;
-      GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff2_w2, L.ff2_b2, h->x.p, D, N, D, DFF);
+      GamGemmArgs g2 = gemm_args(h->hbuf.p, DFF, L.ff2_w2, L.ff2_b2, h->x.p, D, NR, D, DFF);
       g2.R = h->x.p; g2.ldr = D; g2.alpha = 0.5f;
       sp_a(g2);
       if (int r = gemm(h, s, g2, GAM_ACT_NONE, GAM_PF_GEMM, &L.s_ff2_w2, &pend)) return r;
@@ -1235,7 +1272,7 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
 
   // Small batches: replay the layer sequence as one hipGraph (see gam_handle::use_graph).
   bool replayed = false;
-  if (h->use_graph && !h->prof_on && nl > 0 && N < h->graph_max_rows) {
+  if (h->use_graph && !h->prof_on && nl > 0 && N < h->graph_max_rows && !packed) {   // (packed rows: the row count is part of every launch)
     // every workspace the captured launches touch must exist before the capture (no allocation inside)
     if (int r = ensure(h, h->splitk_ws, (size_t)16 * N * std::max(DFF, 2 * D) + 64)) return r;
     const GamSpForce& frc = gam_sp_force();   // (a plan forced through gam_tune_sp after a capture must not replay the old tiling)
@@ -1277,11 +1314,17 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
   // ------------------------------ outputs ------------------------------
   {
     ProfScope ps(h, s, GAM_PF_MISC, (double)B * Tv * D * 8.0);
-    if (encoded) {
+    if (encoded && packed) {
+      hipLaunchKernelGGL(gam_unpack_transpose_kernel, dim3(gam_cdiv(D, 32), gam_cdiv(Tv, 32), B), dim3(256), 0, s, h->x.p, cu, len2, encoded, Tv, D);
+      HIPCHK(h, hipGetLastError());
+    } else if (encoded) {
       hipError_t e = gam_launch_transpose(h->x.p, encoded, B, Tv, D, (size_t)Ta * D, D, (size_t)D * Tv, Tv, s);
       if (e != hipSuccess) return fail(h, -2, "transpose launch: %s", hipGetErrorString(e));
     }
-    if (tokens_out)
+    if (tokens_out && packed) {
+      hipLaunchKernelGGL(gam_unpack_rows_kernel, dim3(std::min(4096, gam_cdiv(B * Tv * (D / 4), 256))), dim3(256), 0, s, h->x.p, cu, len2, tokens_out, B, Tv, D);
+      HIPCHK(h, hipGetLastError());
+    } else if (tokens_out)
       HIPCHK(h, hipMemcpy2DAsync(tokens_out, (size_t)Tv * D * 4, h->x.p, (size_t)Ta * D * 4, (size_t)Tv * D * 4, B, hipMemcpyDeviceToDevice, s));
     if (enc_len) HIPCHK(h, hipMemcpyAsync(enc_len, elen, (size_t)B * sizeof(int), hipMemcpyDeviceToDevice, s));
   }
@@ -1296,6 +1339,11 @@ int gam_encode(gam_handle* h, const float* feat, const int64_t* feat_len, int B,
 int gam_encode_ex(gam_handle* h, const float* feat, const int64_t* feat_len, int B, int64_t T, float* encoded, int32_t* enc_len,
                   int n_layers_run, float* tokens_out, void* stream) {
   return encode_impl(h, feat, feat_len, B, T, encoded, enc_len, n_layers_run, tokens_out, (hipStream_t)stream);
+}
+
+int gam_encode_varlen(gam_handle* h, const float* feat, const int64_t* feat_len, const int64_t* feat_len_host, int B, int64_t T,
+                      float* encoded, int32_t* enc_len, int n_layers_run, float* tokens_out, void* stream) {
+  return encode_impl(h, feat, feat_len, B, T, encoded, enc_len, n_layers_run, tokens_out, (hipStream_t)stream, feat_len_host);
 }
 
 // -----------------------------------------------------------------------------------
@@ -1442,13 +1490,11 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
       ca.wout_slice_in_lds = (size_t)nV * (JH + 4) * 4 + gam_rnnt_cluster_smem(a.H, JH, a.V, C, nr, 0) <= 96 * 1024 ? 1 : 0;
       ca.wpred_slice_in_lds = gam_rnnt_cluster_smem(a.H, JH, a.V, C, nr, ca.wout_slice_in_lds, 1) <= 150 * 1024 ? 1 : 0;
       size_t sm = gam_rnnt_cluster_smem(a.H, JH, a.V, C, nr, ca.wout_slice_in_lds, ca.wpred_slice_in_lds);
-      // A decode workgroup OWNS its compute unit: it asks for the CU's whole LDS (160 KB), so no other workgroup that uses LDS
-      // -- of this launch or of ANOTHER stream's kernel -- is placed beside it.  r05 finding (tools/overlap_debug*.py,
-      // profiles/r05_overlap_investigation.txt): with the decode on a side stream beside the next batch's encoder, a decode
-      // workgroup that shared its CU with a workgroup of the small-tile LDS-DMA GEMM (gam_gemm_sp_kernel, 64-96 KB of LDS:
-      // both fit) came out with a slightly perturbed predictor state in 5-30 % of the launches -- never with the GPU to
-      // itself, never beside the 112-128 KB tiles (which cannot share a CU with it), never with this line.  The grid is at
-      // most one workgroup per CU anyway (C is chosen that way), so the claim costs nothing.
+      // GAM_RNNT_EXCLUSIVE=1: a decode workgroup asks for the CU's whole LDS (160 KB), so no other workgroup that uses LDS -- of this launch or
+      // of ANOTHER stream's kernel -- is placed beside it.  r05 shipped this as the protection against a perturbation of co-resident decode
+      // workgroups whose mechanism was unknown; r06 found it (hipcc had packed the gate rows' FMA chains into v_pk_fma_f32 op_sel:[0,1,0],
+      // whose low result is wrong in lanes 48..63 beside another wave's MFMAs: gigaam_amd/build.py) and removed the instruction, so the
+      // default is the kernel's own LDS size again; the switch stays as an A/B (profiles/r06_exclusive_ab.txt: no time difference).
       if (h->rnnt_exclusive && sm <= 160 * 1024) sm = 160 * 1024;
       const size_t xg = gam_rnnt_cluster_xgranules(a.H, JH, C) * (size_t)B;
       if (sm <= 160 * 1024 && need <= 8) {

@@ -15,6 +15,7 @@
 // per-lane multiply and the epilogue stores 16 B per lane.
 #pragma once
 #include "gam_common.h"
+#include "gam_pack.h"
 
 #define GAM_ATT_DK 48
 #define GAM_ATT_KT 64          // keys per LDS tile
@@ -28,6 +29,7 @@ struct GamAttnArgs {
   float* ctx;       // [B*Ta, ldo]
   int ctx_split;    // ctx in the sp32 GEMM-operand layout (ldo % 32 == 0)
   const int* lens;  // valid frames per utterance (keys), or null = no mask
+  const int* cu;    // packed rows (gam_pack.h): first row of every utterance; null = padded layout (b * Ta)
   int B, Ta, Tv, H;
   long ldq, ldv, ldo;
   float scale;      // 1/sqrt(d_k); the kernels work in the log2 domain (scale * log2 e, v_exp_f32)
@@ -51,7 +53,10 @@ __global__ __launch_bounds__(256) void gam_attn_f32_kernel(GamAttnArgs a) {
   const int b = blockIdx.z, h = blockIdx.y;
   int klen = a.Tv;
   if (a.lens != nullptr) { const int l = a.lens[b]; klen = l < a.Tv ? l : a.Tv; }
-  const size_t rowbase = (size_t)b * a.Ta;
+  const GamRows ur = gam_rows(a.cu, b, a.Ta, klen);
+  if ((int)blockIdx.x * 128 >= ur.lim) return;
+  const size_t rowbase = ur.base;
+  const int rlim = ur.lim;
   const int qw0 = blockIdx.x * 128 + wave * 32;
 
   // Q fragments (B operand of S^T): lane (query li, kk lg) holds d = 16*s + 4*lg + e
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(256) void gam_attn_f32_kernel(GamAttnArgs a) {
   for (int j = 0; j < 2; ++j) {
     const int qi = qw0 + j * 16 + li;
     qrow[j] = qi;
-    const int qc = qi < a.Ta ? qi : a.Ta - 1;
+    const int qc = qi < rlim ? qi : rlim - 1;
     const float* qp = a.q + (rowbase + qc) * a.ldq + h * DK + 4 * lg;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(256) void gam_attn_f32_kernel(GamAttnArgs a) {
       const int idx = tid + i * 256;       // 0..767
       const int kr = idx / 12, c4 = (idx - kr * 12) * 4;
       int key = kt0 + kr;
-      key = key < a.Ta ? key : a.Ta - 1;
+      key = key < rlim ? key : rlim - 1;
       const float4 kv = *reinterpret_cast<const float4*>(a.k + (rowbase + key) * a.ldq + h * DK + c4);
       const float4 vv = *reinterpret_cast<const float4*>(a.v + (rowbase + key) * a.ldv + h * DK + c4);
       *reinterpret_cast<float4*>(&Ks[kr * GAM_ATT_KLD + c4]) = kv;
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256) void gam_attn_f32_kernel(GamAttnArgs a) {
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = l > 0.f ? 1.0f / l : 0.f;   // klen == 0 -> zeros
-    if (qrow[j] < a.Ta) {
+    if (qrow[j] < rlim) {
 #pragma unroll
       for (int d = 0; d < 3; ++d)
         gam_store4(a.ctx, (size_t)(rowbase + qrow[j]) * a.ldo, h * DK + 4 * lg + 16 * d, o[d][j][0] * inv, o[d][j][1] * inv,

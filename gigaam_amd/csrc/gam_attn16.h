@@ -57,7 +57,10 @@ __global__ __launch_bounds__(256, NJ == 1 ? (REL ? 3 : 4) : 2) void gam_attn_f16
   const int b = blockIdx.z, h = blockIdx.y;
   int klen = a.Tv;
   if (a.lens != nullptr) { const int l = a.lens[b]; klen = l < a.Tv ? l : a.Tv; }
-  const size_t rowbase = (size_t)b * a.Ta;
+  const GamRows ur = gam_rows(a.cu, b, a.Ta, klen);   // (packed rows: only the utterance's own frames exist)
+  if ((int)blockIdx.x * (64 * NJ) >= ur.lim) return;  // a query block behind the last frame (whole workgroup: no barrier is left behind)
+  const size_t rowbase = ur.base;
+  const int rlim = ur.lim;
   const int qw0 = blockIdx.x * (64 * NJ) + wave * (16 * NJ);
 
   // Q fragments (B operand of S^T), pre-scaled: x32 part d = 8*lg .. +7, x16 part d = 32 + 4*lg .. +3
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256, NJ == 1 ? (REL ? 3 : 4) : 2) void gam_attn_f16
   for (int j = 0; j < NJ; ++j) {
     const int qi = qw0 + j * 16 + li;
     qrow[j] = qi;
-    const int qc = qi < a.Ta ? qi : a.Ta - 1;
+    const int qc = qi < rlim ? qi : rlim - 1;
     const float* qp = a.q + (rowbase + qc) * a.ldq + h * DK;
     const float4 q0 = *reinterpret_cast<const float4*>(qp + 8 * lg);
     const float4 q1 = *reinterpret_cast<const float4*>(qp + 8 * lg + 4);
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256, NJ == 1 ? (REL ? 3 : 4) : 2) void gam_attn_f16
       const int idx = tid + i * 256;       // 0..767
       const int kr = idx / 12, c4 = (idx - kr * 12) * 4;
       int key = kt0 + kr;
-      key = key < a.Ta ? key : a.Ta - 1;
+      key = key < rlim ? key : rlim - 1;
       kreg[i] = *reinterpret_cast<const float4*>(a.k + (rowbase + key) * a.ldq + h * DK + c4);
     }
 #pragma unroll
@@ -121,8 +124,8 @@ __global__ __launch_bounds__(256, NJ == 1 ? (REL ? 3 : 4) : 2) void gam_attn_f16
       it = it < 32 * 12 ? it : 32 * 12 - 1;
       const int kp = it / 12, c4 = (it - kp * 12) * 4;
       int k0 = kt0 + 2 * kp, k1 = k0 + 1;
-      k0 = k0 < a.Ta ? k0 : a.Ta - 1;
-      k1 = k1 < a.Ta ? k1 : a.Ta - 1;
+      k0 = k0 < rlim ? k0 : rlim - 1;
+      k1 = k1 < rlim ? k1 : rlim - 1;
       vreg[i][0] = *reinterpret_cast<const float4*>(a.v + (rowbase + k0) * a.ldv + h * DK + c4);
       vreg[i][1] = *reinterpret_cast<const float4*>(a.v + (rowbase + k1) * a.ldv + h * DK + c4);
     }
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256, NJ == 1 ? (REL ? 3 : 4) : 2) void gam_attn_f16
         const int idx = tid + i * 256;       // 0..767
         const int kr = idx / 12, c4 = (idx - kr * 12) * 4;
         int key = kt0 + kr;
-        key = key < a.Ta ? key : a.Ta - 1;
+        key = key < rlim ? key : rlim - 1;
         const float4 kv = *reinterpret_cast<const float4*>(a.k + (rowbase + key) * a.ldq + h * DK + c4);
         gam_half4 hi, lo;
         gam_split4((f32x4){kv.x, kv.y, kv.z, kv.w}, hi, lo);
@@ -148,8 +151,8 @@ __global__ __launch_bounds__(256, NJ == 1 ? (REL ? 3 : 4) : 2) void gam_attn_f16
       for (int it = tid; it < 32 * 12; it += 256) {
         const int kp = it / 12, c4 = (it - kp * 12) * 4;
         int k0 = kt0 + 2 * kp, k1 = k0 + 1;
-        k0 = k0 < a.Ta ? k0 : a.Ta - 1;
-        k1 = k1 < a.Ta ? k1 : a.Ta - 1;
+        k0 = k0 < rlim ? k0 : rlim - 1;
+        k1 = k1 < rlim ? k1 : rlim - 1;
         const float4 v0 = *reinterpret_cast<const float4*>(a.v + (rowbase + k0) * a.ldv + h * DK + c4);
         const float4 v1 = *reinterpret_cast<const float4*>(a.v + (rowbase + k1) * a.ldv + h * DK + c4);
         gam_half4 h0, l0, h1, l1;
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(256, NJ == 1 ? (REL ? 3 : 4) : 2) void gam_attn_f16
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
     const float inv = l > 0.f ? 1.0f / l : 0.f;   // klen == 0 -> zeros
-    if (qrow[j] < a.Ta) {
+    if (qrow[j] < rlim) {
 #pragma unroll
       for (int d = 0; d < 3; ++d)
         gam_store4(a.ctx, (size_t)(rowbase + qrow[j]) * a.ldo, h * DK + 4 * lg + 16 * d, o[d][j][0] * inv, o[d][j][1] * inv,

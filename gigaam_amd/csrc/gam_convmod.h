@@ -8,6 +8,7 @@
 // N = 16 032, d = 768).
 #pragma once
 #include "gam_common.h"
+#include "gam_pack.h"
 #include <type_traits>
 
 struct GamConvModArgs {
@@ -18,6 +19,7 @@ struct GamConvModArgs {
   const float* n_scale;  // BN: gamma/sqrt(var+eps)   | LN: weight
   const float* n_shift;  // BN: beta - mean*scale     | LN: bias
   const int* lens;     // valid frames per utterance
+  const int* cu;       // packed rows (gam_pack.h): first row of every utterance; null = padded layout (b * Ta)
   int B, Ta, Tv, d, ks;
   float eps;
   int z_split;   // z in the sp32 GEMM-operand layout
@@ -44,7 +46,10 @@ __global__ __launch_bounds__(512, 4) void gam_convmod_bn_kernel(GamConvModArgs a
   const int b = blockIdx.z, c = blockIdx.y * 64 + q * 4, t0 = blockIdx.x * TT;
   int klen = a.lens[b];
   klen = klen < a.Tv ? klen : a.Tv;
-  const size_t rowbase = (size_t)b * a.Ta;
+  const GamRows ur = gam_rows(a.cu, b, a.Ta, klen);
+  if (t0 >= ur.lim) return;      // a tile behind the utterance's last row (whole workgroup)
+  const size_t rowbase = ur.base;
+  const int rlim = ur.lim;
   // GLU'd input tile: row r of the tile is loaded by row group r % 16 (clamped row, value masked afterwards --
   // a per-element "if in range: load" keeps one load outstanding per thread)
   constexpr int NLD = ROWS / NRG;     // (ROWS is rounded up to whole row groups: no "row in range" branch anywhere)
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(512, 4) void gam_convmod_bn_kernel(GamConvModArgs a
 #pragma unroll
   for (int u = 0; u < NLD; ++u) {
     const int t = t0 - PAD + rg + NRG * u;
-    const int tc = t < 0 ? 0 : (t < a.Ta ? t : a.Ta - 1);
+    const int tc = t < 0 ? 0 : (t < rlim ? t : rlim - 1);
     const float* up = a.u + (rowbase + tc) * (size_t)(2 * a.d);
     ua[u] = *reinterpret_cast<const f32x4*>(up + c);
     ub[u] = *reinterpret_cast<const f32x4*>(up + a.d + c);
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(512, 4) void gam_convmod_bn_kernel(GamConvModArgs a
     const int t = t0 + rg * OUT + i;
     const f32x4 y = (acc[i] + bias) * sc + sh;
     const float v0 = gam_silu(y.x), v1 = gam_silu(y.y), v2 = gam_silu(y.z), v3 = gam_silu(y.w);
-    if (t < a.Ta) {
+    if (t < rlim) {
       gam_range_note(a.range_flag, v0, v1, v2, v3);   // z feeds the pointwise-conv2 GEMM unscaled
       gam_store4(a.z, (rowbase + t) * (size_t)a.d, c, v0, v1, v2, v3, a.z_split);
     }
@@ -140,7 +145,10 @@ __global__ __launch_bounds__(256) void gam_convmod_ln_kernel(GamConvModArgs a) {
   const int b = blockIdx.y, t0 = blockIdx.x * TT;
   int klen = a.lens[b];
   klen = klen < a.Tv ? klen : a.Tv;
-  const size_t rowbase = (size_t)b * a.Ta;
+  const GamRows ur = gam_rows(a.cu, b, a.Ta, klen);
+  if (t0 >= ur.lim) return;      // a tile behind the utterance's last row (whole workgroup)
+  const size_t rowbase = ur.base;
+  const int rlim = ur.lim;
   // GLU'd input tile, 4 rows (up to 32 loads per thread) in flight at a time; rows / channels out of
   // range are clamped for the load and masked afterwards (no per-element branch around a load)
   for (int r0 = 0; r0 < ROWS; r0 += 4) {
@@ -148,7 +156,7 @@ __global__ __launch_bounds__(256) void gam_convmod_ln_kernel(GamConvModArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int t = t0 - PAD + r0 + q;
-      const int tc = t < 0 ? 0 : (t < a.Ta ? t : a.Ta - 1);
+      const int tc = t < 0 ? 0 : (t < rlim ? t : rlim - 1);
       const float* up = a.u + (rowbase + tc) * (size_t)(2 * a.d);
 #pragma unroll
       for (int ci = 0; ci < MAXC; ++ci) {
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(256) void gam_convmod_ln_kernel(GamConvModArgs a) {
 #pragma unroll
       for (int i = 0; i < TT; ++i) {
         const int t = t0 + i;
-        if (t < a.Ta) gam_store1(a.z, (rowbase + t) * (size_t)a.d, c, gam_silu((y[ci][i] - mean[i]) * rstd[i] * g + be), a.z_split);
+        if (t < rlim) gam_store1(a.z, (rowbase + t) * (size_t)a.d, c, gam_silu((y[ci][i] - mean[i]) * rstd[i] * g + be), a.z_split);
       }
     }
   }
@@ -247,12 +255,15 @@ __global__ __launch_bounds__(256) void gam_convmod_ln4_kernel(GamConvModArgs a) 
   const int c = live ? tid * 4 : 0;
   int klen = a.lens[b];
   klen = klen < a.Tv ? klen : a.Tv;
-  const size_t rowbase = (size_t)b * a.Ta;
+  const GamRows ur = gam_rows(a.cu, b, a.Ta, klen);
+  if (t0 >= ur.lim) return;      // a tile behind the utterance's last row (whole workgroup)
+  const size_t rowbase = ur.base;
+  const int rlim = ur.lim;
   f32x4 ua[ROWS], ub[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     const int t = t0 - PAD + r;
-    const int tc = t < 0 ? 0 : (t < a.Ta ? t : a.Ta - 1);
+    const int tc = t < 0 ? 0 : (t < rlim ? t : rlim - 1);
     const float* up = a.u + (rowbase + tc) * (size_t)(2 * a.d);
     ua[r] = *reinterpret_cast<const f32x4*>(up + c);
     ub[r] = *reinterpret_cast<const f32x4*>(up + a.d + c);
@@ -312,7 +323,7 @@ __global__ __launch_bounds__(256) void gam_convmod_ln4_kernel(GamConvModArgs a) 
 #pragma unroll
   for (int i = 0; i < TT; ++i) {
     const int t = t0 + i;
-    if (t < a.Ta) {
+    if (t < rlim) {
       const float v0 = gam_silu((y[i].x - mean[i]) * rstd[i] * gm.x + be.x), v1 = gam_silu((y[i].y - mean[i]) * rstd[i] * gm.y + be.y);
       const float v2 = gam_silu((y[i].z - mean[i]) * rstd[i] * gm.z + be.z), v3 = gam_silu((y[i].w - mean[i]) * rstd[i] * gm.w + be.w);
       gam_range_note(a.range_flag, v0, v1, v2, v3);   // z feeds the pointwise-conv2 GEMM unscaled

@@ -50,6 +50,9 @@ struct GamGemmArgs {
   // row remap: out_row = (m / rpb) * out_rpb + (m % rpb) + out_shift; rows with
   // (m % rpb) >= rows_valid are skipped
   int remap, out_rpb, out_shift, rows_valid;
+  // packed-row batches (gam_pack.h): the stem still runs on the padded layout, but a row tile that lies wholly inside ONE utterance's
+  // padding frames (t >= lens[b] for all its rows) produces nothing the gather behind the stem reads -- gam_gemm_sp_kernel returns at once
+  int skip_pad;
   // split-fp16 operand planes of W (gam_gemm16.h): W * 2^wshift = Whi + Wlo (+ ~2^-22 |W|)
   const _Float16* Whi;
   const _Float16* Wlo;

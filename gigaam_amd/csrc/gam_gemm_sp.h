@@ -105,7 +105,14 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
   const int xcd = bid & 7;
   const int lid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
   int tm = lid / nbn, tn = lid % nbn;
-  if (g.tile_order > 0 && nbn % g.tile_order == 0) {
+  if (g.skip_pad) {
+    // An XCD's CONTIGUOUS share of the tiles is a run of utterances: the XCDs of the short ones would finish early and wait for the one that
+    // holds the longest (measured: no gain at all).  The tiles are dealt round robin over the XCDs instead.  (Keeping the column tiles of a
+    // row tile on one XCD -- they share the A patch -- measured worse: conv2 0.955 of the padded launch against 0.905, r06_packed_rows_ab.txt.)
+    tm = bid / nbn;
+    tn = bid % nbn;
+  }
+  if (g.tile_order > 0 && nbn % g.tile_order == 0 && !g.skip_pad) {
     // r05 experiment (GAM_SP_ORDER = G): groups of G column tiles OUTERMOST -- an XCD's contiguous share of the tile sequence
     // then stays inside one group, i.e. G x BN rows of W (G = 3, BN = 256, K = 768: 2.4 MB, resident in the XCD's 4 MB L2)
     // while the row tiles stream past; same tiles, same arithmetic: bit-identical results (profiles/r05_gemm_tile_order.txt)
@@ -116,6 +123,11 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
   }
   const int m0 = tm * BM;
   const int n0 = tn * BN;
+  if (g.skip_pad && g.lens != nullptr) {   // (uniform: the whole workgroup leaves before its first DMA and barrier)
+    const int mlast = m0 + BM - 1 < g.M ? m0 + BM - 1 : g.M - 1;
+    const int b0 = m0 / g.rpb;
+    if (b0 == mlast / g.rpb && (m0 - b0 * g.rpb) / g.fdiv >= g.lens[b0]) return;
+  }
   GAM_SP_TL(0);
 
   // ---- DMA sources.  Piece q of an operand = tile rows 8q .. 8q+7; this wave moves pieces

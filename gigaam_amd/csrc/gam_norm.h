@@ -38,6 +38,7 @@ struct GamLnArgs {
   const float* presid;  // [rows][d]
   float palpha;
   float* xstore;        // where the finished row goes (MODE 0 / 1; MODE 2 overwrites it with out1 anyway)
+  const int* row_t;     // packed rows (gam_pack.h): the frame index of every row for the rotary table; null = padded layout (row % ta)
 };
 
 // max |v| of a row held as float4[GAM_LN_MAXJ] across a wave
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void gam_layernorm_kernel(GamLnArgs a) {
   if (EARLY && MODE == 2) gam_ln_load_wb(p2, a.w2, a.b2, a.d, lane);
   float4 rc4[GAM_LN_MAXJ], rs4[GAM_LN_MAXJ];
   if (EARLY && MODE == 1) {
-    int t = row % a.ta;
+    int t = a.row_t != nullptr ? a.row_t[row] : row % a.ta;
     t = t < a.rope_rows ? t : a.rope_rows - 1;   // stride-padding rows past pos_emb_max_len are don't-care frames
     const int half = a.dk >> 1;
 #pragma unroll
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256) void gam_layernorm_kernel(GamLnArgs a) {
     }
     __syncthreads();
     const int half = a.dk >> 1;
-    int t = row % a.ta;
+    int t = a.row_t != nullptr ? a.row_t[row] : row % a.ta;
     t = t < a.rope_rows ? t : a.rope_rows - 1;
 #pragma unroll
     for (int j = 0; j < GAM_LN_MAXJ; ++j) {

@@ -65,12 +65,14 @@ class ConformerEncoder(_EngineModule):
     def _cfg_trees(self):
         return None, self.cfg, None
 
-    def forward_f32(self, audio_signal: Tensor, length: Tensor) -> Tuple[Tensor, Tensor]:
-        """The kernels' own output: fp32 whatever the module's storage dtype is (what the heads of this package consume)."""
-        return self.engine.encode(audio_signal, length)
+    def forward_f32(self, audio_signal: Tensor, length: Tensor, host_lengths=None) -> Tuple[Tensor, Tensor]:
+        """The kernels' own output: fp32 whatever the module's storage dtype is (what the heads of this package consume).
+        ``host_lengths`` (not in the reference's signature): ``length`` as host integers -- a ragged batch then runs on its valid frames only
+        (engine.encode); a ``length`` tensor that lives on the CPU is used for it automatically."""
+        return self.engine.encode(audio_signal, length, host_lengths=host_lengths)
 
-    def forward(self, audio_signal: Tensor, length: Tensor) -> Tuple[Tensor, Tensor]:
-        enc, elen = self.forward_f32(audio_signal, length)
+    def forward(self, audio_signal: Tensor, length: Tensor, host_lengths=None) -> Tuple[Tensor, Tensor]:
+        enc, elen = self.forward_f32(audio_signal, length, host_lengths)
         if self._anchor.dtype != torch.float32:   # .half()-ed encoder (fp16_encoder=True): fp16 at the boundary
             enc = enc.to(self._anchor.dtype)
         return enc, elen

@@ -183,7 +183,7 @@ class HipEngine:
         out = C.c_int(0)
         with torch.cuda.device(self.device):
             self._check(self.lib.gam_range_flag(self._h, C.byref(out), self._stream()), "gam_range_flag")
-        return bool(out.value)
+        return self._flag_of(out.value)
 
     def _counts_with_flag(self, b: int) -> Tuple[Tensor, Tensor]:
         """counts i32 [b] as a view of a [b + 1] buffer whose last element receives the range flag
@@ -215,6 +215,14 @@ class HipEngine:
         return st
 
     @staticmethod
+    def _flag_of(word: int) -> bool:
+        """The handle's flag word: bit 0 = a split-fp16 operand left fp16's range (the caller repeats the batch on the exact path);
+        bit 1 = gam_encode_varlen was given host lengths SHORTER than the device's (the batch is incomplete: an error, not a fallback)."""
+        if int(word) & 2:
+            raise GigaAMHipError("encode(host_lengths=...): a host length is shorter than the device length of the same utterance")
+        return bool(int(word) & 1)
+
+    @staticmethod
     def collect(dec, frames: Optional[Tensor] = None, counts: Optional[Tensor] = None):
         """``Decoded`` -> ([(ids, frames)] host lists, range_flag).  One blocking D2H for the counts AND the split-fp16 range
         flag accumulated up to this decode, one for the used part of ids / frames, both on a side stream that waits for the
@@ -230,7 +238,7 @@ class HipEngine:
             with torch.cuda.stream(side):
                 side.wait_event(evt)
                 n = src.cpu().tolist()
-                flag = bool(n.pop()) if ext is not None else False
+                flag = HipEngine._flag_of(n.pop()) if ext is not None else False
                 width = max(n) if n else 0
                 ids_h, fr_h = ids[:, :width].cpu(), frames[:, :width].cpu()
             for t in (ids, frames, src):
@@ -241,7 +249,7 @@ class HipEngine:
                 # CURRENT stream is not ordered behind -- wait for the whole device rather than read half-written counts
                 torch.cuda.synchronize(ids.device)
             n = src.cpu().tolist()
-            flag = bool(n.pop()) if ext is not None else False
+            flag = HipEngine._flag_of(n.pop()) if ext is not None else False
             width = max(n) if n else 0
             ids_h, fr_h = ids[:, :width].cpu(), frames[:, :width].cpu()
         if n and min(n) < 0:   # cannot happen: gam_rnnt_greedy repairs failed clusters itself (gam_api.hip launch_single)
@@ -267,7 +275,20 @@ class HipEngine:
         self._check(rc, "gam_frontend")
         return feat, flen
 
-    def encode(self, feat: Tensor, length: Tensor, n_layers_run: int = -1, want_tokens: bool = False):
+    def host_feat_lengths(self, wav_lengths) -> Optional[list]:
+        """Feature-frame counts of a batch from its sample counts, ON THE HOST (``FeatureExtractor.out_len``, gam_feat_frames) -- what
+        ``encode(host_lengths=...)`` wants for a ragged batch.  None when the lengths live on the GPU (reading them would be a host sync)."""
+        if isinstance(wav_lengths, Tensor):
+            if wav_lengths.is_cuda:
+                return None
+            wav_lengths = wav_lengths.tolist()
+        return [self.feat_frames(int(n)) for n in wav_lengths]
+
+    def encode(self, feat: Tensor, length: Tensor, n_layers_run: int = -1, want_tokens: bool = False, host_lengths=None):
+        """``host_lengths``: the same feature lengths as ``length`` as host integers (``host_feat_lengths``).  With them a ragged batch's layers
+        run on its valid frames only (gam_encode_varlen: packed rows); without them -- or for an equal-length batch -- on B x T'max rows."""
+        if host_lengths is None and isinstance(length, Tensor) and not length.is_cuda:
+            host_lengths = length.tolist()        # the caller's lengths are on the host anyway
         feat = self._dev(feat, torch.float32)
         length = self._dev(length, torch.int64)
         b, f, t = feat.shape
@@ -278,7 +299,13 @@ class HipEngine:
         elen = torch.empty((b,), dtype=torch.int32, device=self.device)
         tok = torch.empty((b, tp, self.cfg.d_model), dtype=torch.float32, device=self.device) if want_tokens else None
         with torch.cuda.device(self.device):
-            if n_layers_run < 0 and not want_tokens:
+            if host_lengths is not None and b > 1:
+                if len(host_lengths) != b:
+                    raise GigaAMHipError(f"host_lengths has {len(host_lengths)} entries for a batch of {b}")
+                hl = (C.c_int64 * b)(*[int(v) for v in host_lengths])
+                rc = self.lib.gam_encode_varlen(self._h, _ptr(feat), _ptr(length), hl, b, t, _ptr(enc), _ptr(elen), n_layers_run, _ptr(tok),
+                                                self._stream())
+            elif n_layers_run < 0 and not want_tokens:
                 rc = self.lib.gam_encode(self._h, _ptr(feat), _ptr(length), b, t, _ptr(enc), _ptr(elen), self._stream())
             else:
                 rc = self.lib.gam_encode_ex(self._h, _ptr(feat), _ptr(length), b, t, _ptr(enc), _ptr(elen),

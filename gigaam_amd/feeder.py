@@ -76,6 +76,8 @@ class BatchFeeder:
         self._pin_len = [torch.empty((max_b,), dtype=torch.int64).pin_memory() for _ in range(2)]
         self._dev = [torch.empty((max_b * max_l,), dtype=torch.float32, device=self.device) for _ in range(2)]
         self.collate_seconds, self.batches_staged = 0.0, 0     # host time spent assembling batches (bench.py reports it)
+        self.host_lengths: List[int] = []   # sample counts of the batch yielded last, as host integers (model.launch_batch(host_lengths=...):
+                                            # a ragged batch then runs on its valid frames only, engine.encode)
         self._ready = [None, None]      # H2D completion event of the copy last issued from pinned slot i
         self._consumed = [None, None]   # recorded on the consumer's stream once it has enqueued the readers of device slot i
 
@@ -100,7 +102,7 @@ class BatchFeeder:
             ready = torch.cuda.Event()
             ready.record(self._copy_stream)
         self._ready[slot] = ready
-        return wav, ln, ready
+        return wav, ln, ready, [int(v) for v in lens.tolist()]
 
     def __iter__(self) -> Iterator[Tuple[Tensor, Tensor]]:
         it = batches(self.segments, self.batch_size)
@@ -108,7 +110,7 @@ class BatchFeeder:
         nxt = next(it, None)
         staged = self._stage(slot, nxt) if nxt is not None else None
         while staged is not None:
-            wav, ln, ready = staged
+            wav, ln, ready, host_l = staged
             nxt = next(it, None)
             other = slot ^ 1
             if nxt is not None:
@@ -118,6 +120,7 @@ class BatchFeeder:
             cur = torch.cuda.current_stream(self.device)
             cur.wait_event(ready)
             ln.record_stream(cur)
+            self.host_lengths = host_l
             yield (wav.clone() if self.copy else wav), ln
             # the consumer is back: everything that reads this slot's views has been enqueued on its stream
             done = torch.cuda.Event()

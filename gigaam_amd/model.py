@@ -100,8 +100,9 @@ class GigaAM(nn.Module):
         the reference wraps the encoder in fp16 autocast on GPU, this path stays fp32).  The public call checks the
         split-fp16 range flag itself (one 4-byte D2H + sync: the caller is about to read the tensor anyway); the
         transcribe paths read the flag together with the decode counts instead (``_encode`` + decoding.finish)."""
+        host = self._host_feat_lengths(feature_lengths)     # (lengths given on the CPU: a ragged batch runs on its valid frames only)
         features, feature_lengths = self.preprocessor(features, feature_lengths)
-        out = self.encoder(features, feature_lengths)
+        out = self.encoder(features, feature_lengths, host) if host is not None else self.encoder(features, feature_lengths)
         eng = getattr(self.encoder, "engine", None)
         if self._check_range and eng is not None and eng.gemm_mode != "f32" and eng.range_flag():
             # an activation outside fp16's range reached a split-fp16 GEMM operand (include/gigaam_hip.h,
@@ -110,10 +111,17 @@ class GigaAM(nn.Module):
             mode = eng.gemm_mode
             eng.set_gemm_mode("f32")
             try:
-                out = self.encoder(features, feature_lengths)
+                out = self.encoder(features, feature_lengths, host) if host is not None else self.encoder(features, feature_lengths)
             finally:
                 eng.set_gemm_mode(mode)
         return out
+
+    def _host_feat_lengths(self, wav_lengths) -> Optional[list]:
+        """Feature-frame counts on the host when the caller's sample counts are on the host (no sync is ever made to get them)."""
+        eng = getattr(self.encoder, "engine", None)
+        if eng is None or not hasattr(eng, "host_feat_lengths"):
+            return None
+        return eng.host_feat_lengths(wav_lengths)
 
     def set_arithmetic(self, mode: str) -> None:
         """Arithmetic of the dense contractions (include/gigaam_hip.h, gam_set_gemm_mode): "f16x3" -- the default, a
@@ -128,12 +136,13 @@ class GigaAM(nn.Module):
         warnings.warn(f"gigaam_amd: activation beyond the split-fp16 GEMM range; {what} recomputed with "
                       "GAM_GEMM_F32 (set GAM_GEMM_MODE=f32 to use that path throughout)", RuntimeWarning, stacklevel=3)
 
-    def _encode(self, wav: Tensor, lengths: Tensor) -> Tuple[Tensor, Tensor]:
+    def _encode(self, wav: Tensor, lengths: Tensor, host_lengths=None) -> Tuple[Tensor, Tensor]:
         """Internal twin of ``forward`` for the transcribe paths: fp32 in, fp32 out whatever ``fp16_encoder`` says (the
         fp16 storage contract of reference __init__.py:188-189 applies to what ``forward`` / ``embed_audio`` RETURN, not
         to what the head consumes here), no host sync and no range check -- the caller reads the flag with the counts."""
+        host = self._host_feat_lengths(lengths if host_lengths is None else host_lengths)
         feat, flen = self.preprocessor(wav.to(torch.float32), lengths)
-        return self.encoder.forward_f32(feat, flen)
+        return self.encoder.forward_f32(feat, flen, host)
 
     def _with_f32_fallback(self, fn: Callable[[], Any], what: str) -> Any:
         """Run ``fn``; if the decode it collects reports the range flag (decoding.RangeOverflow), warn and run it again
@@ -264,13 +273,15 @@ class GigaAMASR(GigaAM):
 
     # ---- the launch / collect pair every transcribe path is built from (public: a driver -- bench.py, shard.run_sharded,
     #      a test -- can interleave them, or replace them to script the decode)
-    def launch_batch(self, wav: Tensor, lengths: Tensor, overlap: bool = False):
+    def launch_batch(self, wav: Tensor, lengths: Tensor, overlap: bool = False, host_lengths=None):
         """Device half of ``transcribe_batch``: frontend + encoder + greedy decode of a collated batch (wav [B,L] zero
         padded, len [B]) launched on the current stream, NO host sync.  Returns an opaque handle for ``collect_batch``.
         ``overlap=True`` says another ``launch_batch`` follows before this one is collected: an RNN-T decode then runs on
         the decode side stream BESIDE the next batch's encoder (decoding.RNNTGreedyDecoding.decode_device)."""
+        # sample counts on the host (given, or ``lengths`` itself still a CPU tensor): a ragged batch then runs on its valid frames only
+        host = host_lengths if host_lengths is not None else (lengths if (isinstance(lengths, Tensor) and not lengths.is_cuda) else None)
         wav, lengths = wav.to(self._device), lengths.to(self._device)
-        encoded, encoded_len = self._encode(wav, lengths)
+        encoded, encoded_len = self._encode(wav, lengths, host)
         return self.decoding.decode_device(self.head, encoded, encoded_len, overlap=overlap), lengths, encoded_len
 
     def collect_batch(self, handle, word_timestamps: bool = False) -> List[Tuple[str, Optional[List[Word]]]]:
@@ -346,8 +357,9 @@ class GigaAMASR(GigaAM):
 
             pending = None
             n_batches = (len(segments) + fr_batch_size - 1) // fr_batch_size
-            for k, (wav, lens) in enumerate(BatchFeeder(segments, fr_batch_size, self._device)):   # pinned, double-buffered H2D
-                handle = self.launch_batch(wav, lens, overlap=k + 1 < n_batches)     # (RNN-T: decode n beside encoder n+1)
+            feeder = BatchFeeder(segments, fr_batch_size, self._device)                           # pinned, double-buffered H2D
+            for k, (wav, lens) in enumerate(feeder):
+                handle = self.launch_batch(wav, lens, overlap=k + 1 < n_batches, host_lengths=getattr(feeder, "host_lengths", None))   # (RNN-T: decode n beside encoder n+1)
                 if pending is not None:
                     emit(pending)
                 pending = handle

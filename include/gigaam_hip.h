@@ -98,6 +98,16 @@ int gam_encode(gam_handle* h, const float* feat, const int64_t* feat_len, int B,
 int gam_encode_ex(gam_handle* h, const float* feat, const int64_t* feat_len, int B, int64_t T,
                   float* encoded, int32_t* enc_len, int n_layers_run, float* tokens_out, void* stream);
 
+/* gam_encode / gam_encode_ex for a RAGGED batch whose lengths the caller also knows on the host (r06): feat_len_host[b] >= the device
+ * value feat_len[b] (the same numbers in practice; NULL = exactly gam_encode_ex).  The Conformer layers then run on the batch's valid
+ * frames only ("packed rows", gigaam_amd/csrc/gam_pack.h; the reference's counterpart is its optional flash-attn varlen attention,
+ * gigaam/utils.py:103-155) instead of B x T'max rows, whenever that drops >= 3 % of the rows; outputs are the same as gam_encode's on every valid
+ * frame (bit-identical at batch sizes without split-K), and frames behind an utterance's end in `encoded` are zero.  The host array is read
+ * before the call returns; still no host synchronisation.  A device length above the host's is reported through the range-flag word (bit 1,
+ * gam_range_flag / gam_range_flag_fetch): that batch's results are then incomplete.  n_layers_run / tokens_out as gam_encode_ex (-1, NULL). */
+int gam_encode_varlen(gam_handle* h, const float* feat, const int64_t* feat_len, const int64_t* feat_len_host, int B, int64_t T,
+                      float* encoded, int32_t* enc_len, int n_layers_run, float* tokens_out, void* stream);
+
 /* CTCHead.forward: encoded f32 [B,d_model,T'] -> log_probs f32 [B,T',V]. */
 int gam_ctc_head(gam_handle* h, const float* encoded, int B, int64_t Tp, float* log_probs, void* stream);
 

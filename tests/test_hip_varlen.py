@@ -1,0 +1,97 @@
+"""GPU: packed rows (gam_encode_varlen, gigaam_amd/csrc/gam_pack.h) -- a ragged batch whose lengths the caller also has on the host runs its
+Conformer layers on the valid frames only.  The reference computes (and masks) every padded frame (gigaam/encoder.py:605-647; its optional
+flash-attn path, gigaam/utils.py:103-155, unpads for attention alone), so the oracle here is the library's own padded path, which the golden /
+live tests pin to the reference: the packed result must equal it on every valid frame -- bit for bit where the GEMM tiling has no split-K slices,
+within 2e-5 where the slice count depends on the row count -- and the reference-anchored ragged tests (tests/test_hip_vs_reference_live.py,
+test_hip_fullsize.py) run through the packed path too, because they hand their lengths over as CPU tensors."""
+import pytest
+import torch
+
+from common import report
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(name, n_layers=2, **kw):
+    from gigaam_amd import synth
+    from gigaam_amd.engine import HipEngine, build_config
+    ck = synth.make_checkpoint(name, seed=3, n_layers=n_layers, **kw)
+    cfg = ck["cfg"]
+    return HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], cfg.get("head")), ck["state_dict"], torch.device("cuda:0")), ck
+
+
+LENS_S = [3.0, 0.33, 2.01, 1.27, 2.56, 0.05, 2.999]     # incl. a 5-frame utterance and tile-edge lengths
+
+
+@pytest.mark.parametrize("name", ["v2_ctc", "v3_e2e_ctc", "v1_ctc"])
+@pytest.mark.parametrize("mode", ["f16x3", "f32"])
+def test_packed_rows_equal_padded_rows(name, mode):
+    from gigaam_amd import synth
+    eng, _ = _engine(name)
+    eng.set_gemm_mode(mode)
+    lens = [int(16000 * s) for s in LENS_S]
+    wav, wlen = synth.synth_audio(len(lens), max(LENS_S), seed=11, lengths=lens)
+    feat, flen = eng.frontend(wav, wlen)
+    host = flen.cpu().tolist()
+    assert host == eng.host_feat_lengths(wlen)                      # the host formula is the device's
+    for n_layers in (0, 1, -1):
+        enc_p, elen_p, tok_p = eng.encode(feat, flen, n_layers_run=n_layers, want_tokens=True)                       # padded rows (no host lengths)
+        enc_k, elen_k, tok_k = eng.encode(feat, flen, n_layers_run=n_layers, want_tokens=True, host_lengths=host)    # packed rows
+        assert torch.equal(elen_p, elen_k)
+        worst = 0.0
+        for b, n in enumerate(elen_p.cpu().tolist()):
+            d = float((enc_p[b, :, :n] - enc_k[b, :, :n]).abs().max()) if n else 0.0
+            worst = max(worst, d, float((tok_p[b, :n] - tok_k[b, :n]).abs().max()) if n else 0.0)
+            assert float(enc_k[b, :, n:].abs().max()) == 0.0 if n < enc_k.shape[2] else True     # zeros behind the last frame
+            assert float(tok_k[b, n:].abs().max()) == 0.0 if n < tok_k.shape[1] else True
+        report("packed_vs_padded", model=name, mode=mode, n_layers=n_layers, max_abs=worst)
+        assert worst <= 2e-5, (name, mode, n_layers, worst)
+    # an upper bound is enough ...
+    enc_u, _ = eng.encode(feat, flen, host_lengths=[h + 7 for h in host])
+    n0 = int(elen_p[0])
+    assert float((enc_u[0, :, :n0] - enc_p[0, :, :n0]).abs().max()) <= 2e-5
+    torch.cuda.synchronize()
+    assert eng.range_flag() is False
+
+
+def test_packed_rows_bit_identical_without_splitk_and_faster_rows():
+    """32 ragged utterances (linspace(4 s, 8 s)): large enough that no GEMM is split along K, so packing changes nothing but which rows exist."""
+    from gigaam_amd import synth
+    eng, _ = _engine("v2_ctc", n_layers=2)
+    lens = [int(16000 * (4.0 + 4.0 * i / 31)) for i in range(32)]
+    wav, wlen = synth.synth_audio(32, 8.0, seed=5, lengths=lens)
+    feat, flen = eng.frontend(wav, wlen)
+    enc_p, elen = eng.encode(feat, flen)
+    enc_k, _ = eng.encode(feat, flen, host_lengths=flen.cpu().tolist())
+    same = all(torch.equal(enc_p[b, :, :n], enc_k[b, :, :n]) for b, n in enumerate(elen.cpu().tolist()))
+    worst = max(float((enc_p[b, :, :n] - enc_k[b, :, :n]).abs().max()) for b, n in enumerate(elen.cpu().tolist()))
+    report("packed_vs_padded_b32", bit_identical=bool(same), max_abs=worst)
+    assert same, worst
+
+
+def test_host_lengths_shorter_than_the_device_lengths_are_reported():
+    from gigaam_amd import synth
+    from gigaam_amd.engine import GigaAMHipError
+    eng, _ = _engine("v2_ctc", n_layers=1)
+    lens = [int(16000 * s) for s in (2.0, 1.0, 0.7, 1.5)]
+    wav, wlen = synth.synth_audio(4, 2.0, seed=2, lengths=lens)
+    feat, flen = eng.frontend(wav, wlen)
+    host = flen.cpu().tolist()
+    host[1] -= 40                                                # ten encoder frames short
+    eng.encode(feat, flen, host_lengths=host)
+    with pytest.raises(GigaAMHipError, match="host length"):
+        eng.range_flag()
+    assert eng.range_flag() is False                             # (cleared by the read)
+
+
+def test_model_api_packs_when_lengths_arrive_on_the_cpu():
+    """model.transcribe_batch / launch_batch with CPU lengths (what load_audio + collate produce) == the same call with GPU lengths (padded rows)."""
+    import gigaam_amd
+    from gigaam_amd import synth
+    ck = synth.make_checkpoint("v2_rnnt", seed=1, n_layers=2)
+    model = gigaam_amd.model_from_checkpoint(ck, "cuda:0")
+    lens = [int(16000 * s) for s in (3.0, 1.1, 2.2, 0.4, 2.9, 1.7)]
+    wav, wlen = synth.synth_audio(6, 3.0, seed=8, lengths=lens)
+    got_cpu = model.transcribe_batch(wav, wlen)
+    got_gpu = model.transcribe_batch(wav.cuda(), wlen.cuda())
+    assert got_cpu == got_gpu

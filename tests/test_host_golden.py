@@ -116,7 +116,7 @@ def test_longform_loop_matches_reference(i, monkeypatch):
         return out
 
     # the loop's public seam: launch_batch (device half, no sync) / collect_batch (host half)
-    monkeypatch.setattr(model, "launch_batch", lambda wav, lens, overlap=False: (wav, lens))
+    monkeypatch.setattr(model, "launch_batch", lambda wav, lens, overlap=False, host_lengths=None: (wav, lens))
     monkeypatch.setattr(model, "collect_batch", lambda h, word_timestamps=False: scripted(h[0], h[1], word_timestamps))
     res = model.transcribe_longform("unused.wav", word_timestamps=c["word_timestamps"], fr_batch_size=c["fr_batch_size"],
                                     speech_regions=[tuple(r) for r in c["regions"]])
@@ -141,7 +141,7 @@ def test_longform_default_vad_falls_back_loudly(monkeypatch):
     monkeypatch.setattr(feeder, "BatchFeeder", _CpuFeeder)
     monkeypatch.setattr(vad_utils.EnergyVAD, "__call__", lambda self, a, sr: [(0.0, 1.0), (1.5, 3.0)])
     model = gigaam_amd.model_from_checkpoint(synth.make_checkpoint("v2_ctc", seed=1, n_layers=1), "cpu")
-    monkeypatch.setattr(model, "launch_batch", lambda wav, lens, overlap=False: (wav, lens))
+    monkeypatch.setattr(model, "launch_batch", lambda wav, lens, overlap=False, host_lengths=None: (wav, lens))
     monkeypatch.setattr(model, "collect_batch", lambda h, word_timestamps=False: [("x", None)] * h[0].shape[0])
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")

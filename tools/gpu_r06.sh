@@ -59,5 +59,42 @@ d = json.loads(sys.stdin.read()); print('config $c exclusive $ex:', d['ms_per_st
     done
   done
   ;;
+s7)  # packed rows: the new tests, then everything ragged
+  ( timeout 900 python -m pytest tests/test_hip_varlen.py -q -x ) > $OUT/varlen.log 2>&1; echo "varlen rc=$?"; tail -25 $OUT/varlen.log
+  ( timeout 1200 python -m pytest tests -q -m gpu -x -k "ragged or live or fullsize or model_api or longform" ) > $OUT/ragged.log 2>&1; echo "ragged rc=$?"; tail -8 $OUT/ragged.log
+  ;;
+s8)  # packed rows: perf A/B on the ragged lines (SURVEY 8d's second run of configs 2 / 3), configs 4 / 5
+  ( timeout 900 python -m pytest tests/test_hip_varlen.py -q -x ) > $OUT/varlen.log 2>&1; echo "varlen rc=$?"; tail -3 $OUT/varlen.log
+  C="--cpu-utts 0 --steps 12 --warmup 3 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power"
+  for rep in 1 2; do
+    for extra in "--config 2 --ragged --no-pack" "--config 2 --ragged" "--config 3 --ragged --no-pack" "--config 3 --ragged" "--config 4 --no-pack --steps 4" "--config 4 --steps 4" "--config 5 --no-pack --steps 4" "--config 5 --steps 4" "--config 2"; do
+      ( timeout 500 python bench.py $C $extra ) 2>> $OUT/ab.err | grep -a '^{' | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('$extra:', d['ms_per_step'], 'ms', d['value'], 'x', d.get('kernel_classes_ms_per_step'))" | tee -a $OUT/ab.txt
+    done
+  done
+  ;;
+s9)  # packed rows after the round-robin dealing of the stem conv's tiles
+  ( timeout 900 python -m pytest tests/test_hip_varlen.py -q -x ) > $OUT/varlen.log 2>&1; echo "varlen rc=$?"; tail -3 $OUT/varlen.log
+  C="--cpu-utts 0 --steps 12 --warmup 3 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power"
+  for rep in 1 2; do
+    for extra in "--config 2 --ragged --no-pack" "--config 2 --ragged" "--config 3 --ragged" "--config 2"; do
+      ( timeout 500 python bench.py $C $extra ) 2>> $OUT/ab.err | grep -a '^{' | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('$extra:', d['ms_per_step'], 'ms', d['value'], 'x', d.get('kernel_classes_ms_per_step'))" | tee -a $OUT/ab.txt
+    done
+  done
+  ;;
+s10)  # kernel traces of the ragged config-2 step, padded vs packed rows
+  cd /tmp
+  for v in nopack pack; do
+    X=""; [ $v = nopack ] && X="--no-pack"
+    ( timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/pf_$v -o b -- python $R/bench.py --config 2 --ragged $X --steps 5 --warmup 2 --cpu-utts 0 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power ) > $OUT/pf_$v.log 2>&1
+    DB=$(find $OUT/pf_$v -name "*.db" | head -1)
+    [ -n "$DB" ] && python $R/tools/rocpd_summary.py $DB $OUT/trace_ragged_${v}_summary.txt "rocprofv3 kernel trace of bench.py --config 2 --ragged ($v)" > /dev/null 2>&1
+  done
+  find $OUT -name "*.db" -delete
+  head -30 $OUT/trace_ragged_pack_summary.txt
+  ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
