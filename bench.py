@@ -505,6 +505,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4, 5], help="BASELINE.json configuration (default 2: the headline)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--gather", default="rccl", choices=["rccl", "torch"], help="the final exchange: gam_gather_ids (C ABI) or torch.distributed")
+    ap.add_argument("--comm-selftest", action="store_true", help="create the communicator behind the C ABI at world --gpus and run ONE gam_gather_ids "
+                    "of a tiny buffer, then exit (tools/scale8.sh runs it first)")
     ap.add_argument("--strict-gather", action="store_true", help="N > 1: fail instead of falling back to torch.distributed when "
                     "gam_comm_create (RCCL behind the C ABI) does not come up on every rank")
     ap.add_argument("--model", default=None, help="override the configuration's model")
@@ -577,6 +579,33 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=n_ranks, device_id=torch.device("cuda", dev_index))
     dev = torch.device("cuda", dev_index)
+
+    if args.comm_selftest:
+        # tools/scale8.sh, first step on an 8-GPU node: the communicator behind the C ABI (gam_comm_create = ncclCommInitRank through
+        # dlopen, never yet run with a world > 1) and ONE gam_gather_ids of a tiny buffer, before any model is built or anything is timed --
+        # a broken communicator then costs a minute, not the session.  Every rank checks what it received.
+        t0 = time.perf_counter()
+        gather, gather_name = make_gather(args.gather, rank, n_ranks, dev, strict=True)
+        rows, width = 3, 5
+        index = torch.arange(rows, dtype=torch.int32, device=dev) + rank * rows
+        counts = torch.full((rows,), rank + 1, dtype=torch.int32, device=dev)
+        ids = (torch.arange(rows * width, dtype=torch.int32, device=dev).reshape(rows, width) + 1000 * rank)
+        frames = ids + 7
+        gi, gc, gids, gfr = gather(index, counts, ids, frames)
+        torch.cuda.synchronize()
+        ok = (gi.cpu().tolist() == list(range(n_ranks * rows)) and gc.cpu().tolist() == [r + 1 for r in range(n_ranks) for _ in range(rows)]
+              and all(int(gids[r * rows, 0]) == 1000 * r and int(gfr[r * rows + rows - 1, width - 1]) == 1000 * r + rows * width - 1 + 7 for r in range(n_ranks)))
+        flag = torch.tensor([1 if ok else 0], device=dev)
+        if n_ranks > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if rank == 0:
+            emit({"comm_selftest": "ok" if int(flag.item()) == 1 else "FAILED", "n_gpus": n_ranks, "gather_path": gather_name,
+                  "rows_exchanged": n_ranks * rows, "seconds": round(time.perf_counter() - t0, 2)}, n_ranks)
+        elif n_ranks > 1:
+            dist.destroy_process_group()
+        if int(flag.item()) != 1:
+            raise SystemExit(f"[bench] rank {rank}: --comm-selftest: the gathered buffers are wrong")
+        return
 
     import gigaam_amd
     from gigaam_amd import synth, workloads

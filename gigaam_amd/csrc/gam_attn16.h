@@ -42,6 +42,12 @@ __device__ __forceinline__ void gam_split8(const float (&v)[8], gam_half8& hi, g
 // K, V, Q and P are rounded to fp16 once, one MFMA per product, fp32 accumulation and fp32 softmax statistics: the arithmetic of
 // an fp16 flash attention (the reference's GPU default runs SDPA under fp16 autocast, /root/reference/gigaam/model.py:34-37).
 // The lo planes are neither computed nor stored (the compiler drops the dead halves of the splits).
+// -DGAM_ATT_PV_TERMS=2 (r06 EXPERIMENT build; never the product): the probabilities enter P.V as fp16 only (the V_hi.P_lo
+// product and the lo half of the P split are dropped: 1/3 of the P.V MFMAs, 2 of the ~10 VALU instructions per score).  Results in
+// profiles/r06_attn_pv2.txt.
+#ifndef GAM_ATT_PV_TERMS
+#define GAM_ATT_PV_TERMS 3
+#endif
 template <bool REL, int TERMS = 3, int NJ = GAM_ATT_NJ>
 __global__ __launch_bounds__(256, NJ == 1 ? (REL ? 3 : 4) : 2) void gam_attn_f16x3_kernel(GamAttnArgs a) {
   constexpr bool LO = TERMS == 3;
@@ -345,7 +351,7 @@ __global__ __launch_bounds__(256, NJ == 1 ? (REL ? 3 : 4) : 2) void gam_attn_f16
         for (int j = 0; j < NJ; ++j) {
           if (LO) {
             o[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[j], o[d][j], 0, 0, 0);
-            o[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[j], o[d][j], 0, 0, 0);
+            if (GAM_ATT_PV_TERMS == 3) o[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[j], o[d][j], 0, 0, 0);
           }
           o[d][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[j], o[d][j], 0, 0, 0);
         }

@@ -96,5 +96,16 @@ s10)  # kernel traces of the ragged config-2 step, padded vs packed rows
   find $OUT -name "*.db" -delete
   head -30 $OUT/trace_ragged_pack_summary.txt
   ;;
+s11)  # EXPERIMENT: two-term P.V attention (-DGAM_ATT_PV_TERMS=2) against the bars that matter: reference ids, every GPU parity test
+  C="--steps 12 --warmup 3 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power"
+  for lib in libgigaam_hip.so libgigaam_hip_pv2.so libgigaam_hip.so libgigaam_hip_pv2.so; do
+    ( GIGAAM_HIP_LIB=$R/gigaam_amd/$lib timeout 600 python bench.py $C ) 2>> $OUT/bench.err | grep -a '^{' | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); c = d.get('cpu_baseline', {})
+print('$lib:', d['ms_per_step'], 'ms', d['value'], 'x attn', d['kernel_classes_ms_per_step'].get('attn'), 'ids vs reference', c.get('gpu_ids_identical'), 'mismatch', c.get('mismatch_logits'), c.get('mismatch_reference_min_margin'))" | tee -a $OUT/pv2.txt
+  done
+  ( GIGAAM_HIP_LIB=$R/gigaam_amd/libgigaam_hip_pv2.so timeout 1500 python -m pytest tests -q -m gpu ) > $OUT/pytest_pv2.log 2>&1; echo "pytest pv2 rc=$?"
+  grep -a "passed\|failed" $OUT/pytest_pv2.log | tail -3 | tee -a $OUT/pv2.txt; grep -a "^FAILED" $OUT/pytest_pv2.log | head -40 | tee -a $OUT/pv2.txt
+  ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac

@@ -13,6 +13,16 @@ python __graft_entry__.py > "$out/build.log" 2>&1 || { echo BUILD FAILED; tail "
 ngpu=$(python -c 'import torch; print(torch.cuda.device_count())')
 echo "visible GPUs: $ngpu"
 fail=0
+# FIRST: the communicator behind the C ABI at the largest world this node offers -- gam_comm_create (ncclCommInitRank through dlopen) has never
+# run with more than one rank -- and one tiny gam_gather_ids, checked on every rank, before anything is built or timed.
+if [ "$ngpu" -ge 2 ]; then
+  nn=$ngpu; [ "$nn" -gt 8 ] && nn=8
+  ( timeout 300 python bench.py --gpus $nn --comm-selftest ) 2> "$out/comm_selftest.err" | grep -a '^{' | tail -1 | tee "$out/comm_selftest.json"
+  grep -q '"comm_selftest": "ok"' "$out/comm_selftest.json" || { echo "COMMUNICATOR SELF-TEST FAILED at world $nn:"; tail -20 "$out/comm_selftest.err"; exit 1; }
+  grep -a -i "nccl\|rccl" "$out/comm_selftest.err" | head -5
+else
+  ( timeout 300 python bench.py --gpus 1 --comm-selftest ) 2> "$out/comm_selftest.err" | grep -a '^{' | tail -1 | tee "$out/comm_selftest.json"
+fi
 run() {   # run <name> <bench args...>
   name=$1; shift
   ( time timeout 900 python bench.py "$@" ) 2> "$out/$name.err" | grep -a '^{' | tail -1 > "$out/$name.json"
