@@ -110,6 +110,7 @@ struct gam_handle {
   int rnnt_cluster = -1;        // GAM_RNNT_CLUSTER: 0 = one workgroup per utterance, N = force N per utterance, -1 = auto
   int rnnt_coop = 1;            // GAM_RNNT_COOP=0: plain instead of cooperative launch of the cluster kernel
   int rnnt_force_timeout = 0;   // GAM_RNNT_FORCE_TIMEOUT=1 (test hook): odd utterances' clusters report a failed hand-off
+  int rnnt_no_repair = 0;       // GAM_RNNT_NO_REPAIR=1 (test hook): no repair pass behind the cluster kernel
   int rnnt_exclusive = 0;       // GAM_RNNT_EXCLUSIVE=1: decode workgroups ask for their CU's whole LDS, so nothing that uses LDS is placed beside them
                                 // (r05's protection; not needed since r06 removed the packed-fp32 instructions that a neighbour's MFMAs disturbed --
                                 // tests/test_hip_hardening.py runs the decode beside another stream's GEMM both ways)
@@ -515,6 +516,7 @@ int gam_create(const gam_config* cfg, int device_id, gam_handle** out) {
   if (const char* e = getenv("GAM_RNNT_EXCLUSIVE")) h->rnnt_exclusive = atoi(e);
   if (const char* e = getenv("GAM_RNNT_COOP")) h->rnnt_coop = atoi(e);
   if (const char* e = getenv("GAM_RNNT_FORCE_TIMEOUT")) h->rnnt_force_timeout = atoi(e);
+  if (const char* e = getenv("GAM_RNNT_NO_REPAIR")) h->rnnt_no_repair = atoi(e);
   {
     int n = 0;
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && n > 0) h->ncu = n;
@@ -1550,7 +1552,7 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
                   resident ? " (resident)" : "", st[T_ROUNDS], st[T_GATES] / 100.0, st[T_XH] / 100.0, st[T_PRED] / 100.0, st[T_XP] / 100.0, st[T_Z] / 100.0,
                   st[T_JOINT] / 100.0, st[T_XA] / 100.0, st[T_COMB] / 100.0, st[T_CTRL] / 100.0);
         }
-        if (getenv("GAM_RNNT_NO_REPAIR")) return 0;   // debug: leave a failed cluster's counts at -1 (HipEngine.collect then raises)
+        if (h->rnnt_no_repair) return 0;   // GAM_RNNT_NO_REPAIR=1 (test hook, read at gam_create): leave a failed cluster's counts at -1 (HipEngine.collect then raises)
         return launch_single(1);   // repair pass: no-op workgroups unless a cluster gave up
       }
     }

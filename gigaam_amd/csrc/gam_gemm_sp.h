@@ -43,7 +43,7 @@
 // prints the distribution (tools/gemm_sp_test.py; profiles/r03_gemm_timeline.txt).
 #if GAM_SP_INSTRUMENT
 #define GAM_SP_TL(i)                                                                  \
-  if ((g.dbg & 16) && g.tlog != nullptr && threadIdx.x == 0) {                        \
+  if ((GAM_SP_DBG(g) & 16) && g.tlog != nullptr && threadIdx.x == 0) {                        \
     g.tlog[(size_t)lid * 8 + (i)] = wall_clock64();                                   \
     if ((i) == 1 || (i) == 2) g.tlog[(size_t)lid * 8 + 4 + (i)] = clock64();          \
     if ((i) == 0) g.tlog[(size_t)lid * 8 + 7] = blockIdx.x;                            \
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
     tm = bid / nbn;
     tn = bid % nbn;
   }
-  if (g.tile_order > 0 && nbn % g.tile_order == 0 && !g.skip_pad) {
+  if (GAM_SP_INSTRUMENT && g.tile_order > 0 && nbn % g.tile_order == 0 && !g.skip_pad) {   // (r05 experiment, instrumented builds only)
     // r05 experiment (GAM_SP_ORDER = G): groups of G column tiles OUTERMOST -- an XCD's contiguous share of the tile sequence
     // then stays inside one group, i.e. G x BN rows of W (G = 3, BN = 256, K = 768: 2.4 MB, resident in the XCD's 4 MB L2)
     // while the row tiles stream past; same tiles, same arithmetic: bit-identical results (profiles/r05_gemm_tile_order.txt)
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
   if (GAM_SP_DBG(g) & 4) { t_start = clock64(); w_start = wall_clock64(); }
   // static priority for the later-dispatched half of the workgroup's waves (the arbitration loser on every phase:
   // MI355X_MICROARCH.md "Two waves per SIMD", item 4)
-  if (g.prio && wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);
+  if (GAM_SP_INSTRUMENT && g.prio && wave >= NWAVES / 2) __builtin_amdgcn_s_setprio(1);   // (r02 experiment, instrumented builds only)
   // in-loop wait: everything but the newest (NS - 2) k-tiles' DMA pieces of this wave has landed (vmcnt counts in issue order)
   constexpr int VMW = (NS - 2) * NG;
   static_assert(VMW < 64, "vmcnt field");
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(128 * NW, NW == 2 ? 2 : 1) void gam_gemm_sp_kernel(
       }
   }
 #if GAM_SP_INSTRUMENT
-  if (g.dbg & 16) { __builtin_amdgcn_s_waitcnt(0x0070); __syncthreads(); }   // stores issued AND acknowledged by every wave
+  if (GAM_SP_DBG(g) & 16) { __builtin_amdgcn_s_waitcnt(0x0070); __syncthreads(); }   // stores issued AND acknowledged by every wave
   GAM_SP_TL(3);
 #endif
 }
@@ -605,7 +605,13 @@ static inline hipError_t gam_launch_gemm_sp(const GamGemmArgs& a_in, int act, hi
   if (a.splitk <= 1) { a.splitk = 0; a.partial = nullptr; }
   const int grid = gam_cdiv(a.M, 64 * mt) * gam_cdiv(a.N, 64 * nw);
   a.ntiles = grid;
+  // the experiment switches GAM_SP_DBG / GAM_SP_PRIO / GAM_SP_ORDER exist in -DGAM_SP_INSTRUMENT=1 builds only: the production kernel
+  // carries none of their branches and the launcher reads no environment variable for them
+#if GAM_SP_INSTRUMENT
   static const int dbg = gam_env_int_once("GAM_SP_DBG"), prio = gam_env_int_once("GAM_SP_PRIO"), order = gam_env_int_once("GAM_SP_ORDER");   // (thread-safe one-time init)
+#else
+  constexpr int dbg = 0, prio = 0, order = 0;
+#endif
   a.dbg = dbg;
   a.prio = prio;
   a.tile_order = order;

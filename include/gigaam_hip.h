@@ -140,7 +140,7 @@ int gam_get_rnnt_cluster(gam_handle* h);
 
 /* Debug aid (r05): FNV-1a hash over one of the decode's scratch buffers as it sits in device memory (synchronises the
  * device).  which: 0 = token-major copy of the encoder output, 1 = encoder projection, 2 = hand-off granules, 3 = CTC
- * logits.  Used by tools/overlap_debug5.py to show that nothing but the decode writes these buffers. */
+ * logits.  (r05's overlap investigation used it to show that nothing but the decode writes these buffers.) */
 int gam_debug_buffer_hash(gam_handle* h, int which, uint64_t* hash_out, int64_t* floats_out);
 
 /* The RNN-T head taken apart (r04): the per-step entry points the reference exposes as sub-modules.  The greedy decode above

@@ -95,3 +95,26 @@ def test_model_api_packs_when_lengths_arrive_on_the_cpu():
     got_cpu = model.transcribe_batch(wav, wlen)
     got_gpu = model.transcribe_batch(wav.cuda(), wlen.cuda())
     assert got_cpu == got_gpu
+
+
+def test_packed_rows_with_an_utterance_of_zero_frames():
+    """v3 frontend (center = False): 160 samples are shorter than one window -> zero feature frames -> zero encoder frames.  The packed index
+    gives that utterance no rows; every kernel must cope (cu[b] == cu[b + 1]) and the other utterances must be unaffected."""
+    from gigaam_amd import synth
+    eng, _ = _engine("v3_e2e_ctc")
+    lens = [32000, 160, 16000, 0, 24000]
+    wav, wlen = synth.synth_audio(len(lens), 2.0, seed=4, lengths=lens)
+    feat, flen = eng.frontend(wav, wlen)
+    host = flen.cpu().tolist()
+    assert host[1] == 0 and host[3] == 0
+    enc_p, elen = eng.encode(feat, flen)
+    enc_k, elen_k = eng.encode(feat, flen, host_lengths=host)
+    assert torch.equal(elen, elen_k) and elen.cpu().tolist()[1] == 0
+    assert bool(torch.isfinite(enc_k).all())
+    for b, n in enumerate(elen.cpu().tolist()):
+        if n:
+            assert float((enc_p[b, :, :n] - enc_k[b, :, :n]).abs().max()) <= 2e-5, b
+    dec = eng.ctc_greedy(enc_k, elen_k)
+    from gigaam_amd.engine import HipEngine
+    rows, flag = HipEngine.collect(dec)
+    assert rows[1] == ([], []) and rows[3] == ([], []) and not flag
