@@ -965,6 +965,11 @@ def main():
         "config": {"workload": workload, "baseline_config": cfgno, "audio_seconds_per_step": round(audio_s, 1),
                    "parallelism": f"dp{n_ranks} (utterance shards, replicated weights, one exchange: {gather_name})"},
     }
+    try:
+        r_run, r_pad = eng.last_encode_rows()
+        line["config"]["token_rows_last_batch"] = {"run": r_run, "padded_layout": r_pad, "packed": bool(r_run < r_pad)}
+    except Exception:   # noqa: BLE001
+        pass
     line["gather_path"] = gather_name        # (top level: a silent fall-back to torch.distributed on the 8-GPU node must be visible)
     if cfgno == 5:
         line["config"]["dealing"] = dealing

@@ -48,6 +48,7 @@ SIGNATURES = {
     "gam_encode": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P]),
     "gam_encode_ex": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, C.c_int, _P, _P]),
     "gam_encode_varlen": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int64), C.c_int, C.c_int64, _P, _P, C.c_int, _P, _P]),
+    "gam_last_encode_rows": (C.c_int, [_P, C.POINTER(C.c_int)]),
     "gam_ctc_head": (C.c_int, [_P, _P, C.c_int, C.c_int64, _P, _P]),
     "gam_ctc_greedy": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, _P, _P, _P, _P]),
     "gam_rnnt_greedy": (C.c_int, [_P, _P, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_int, _P]),

@@ -133,8 +133,10 @@ struct gam_handle {
   DevBuf dec_splitk_ws;                 // split-K partial sums of the DECODE class's GEMMs: a decode may run on a side stream beside
                                         // the next batch's encoder (r05), so it shares no scratch with it (tok / logits / encp / rnnt_x
                                         // are the decode's alone already)
+  int last_rows = 0, last_rows_padded = 0;   // token rows the layers of the last gam_encode* call ran on / would run on padded (gam_last_encode_rows)
   DevBuf pack_idx;      // packed rows (gam_pack.h): cu [B + 1] | row_t [rows] | row_src [rows], as ints
-  int use_pack = 1;     // GAM_PACK=0: ragged batches keep the padded row layout even when the caller gave host lengths (A/B switch)
+  int use_pack = 1;     // GAM_PACK=0: ragged batches keep the padded row layout even when the caller gave host lengths (A/B switch); 2: packed
+                        // rows also below graph_max_rows token rows (tests: the small cases)
   int use_splitk = 1;   // GAM_SPLITK=0 disables split-K for small grids
   int fuse_reduce = 1;  // GAM_FUSE_REDUCE=0: the split-K reduce of a residual GEMM stays a kernel of its own (A/B switch)
   // hipGraph replay of the Conformer-layer launch sequence for small batches (launch-bound: a 5 s clip is
@@ -1018,7 +1020,10 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
   // utterances and callers without host lengths keep the padded layout (and its results, bit for bit).
   bool packed = false;
   int NR = N, Tmax = Ta;
-  if (feat_len_host != nullptr && h->use_pack && B > 1 && B <= 1024) {
+  // (below graph_max_rows the step is launch-bound and replayed as a hipGraph keyed on the padded shape: fewer rows buy nothing there and a
+  //  row count in the key would defeat the replay -- packed rows start where the graph regime ends; GAM_PACK=2 forces them at any size: tests)
+  const bool pack_regime = h->use_pack >= 2 || !h->use_graph || N >= h->graph_max_rows;
+  if (feat_len_host != nullptr && h->use_pack && pack_regime && B > 1 && B <= 1024) {
     long long sum = 0;
     int mx = 0;
     for (int b = 0; b < B; ++b) {
@@ -1029,6 +1034,8 @@ static int encode_impl(gam_handle* h, const float* feat, const int64_t* feat_len
     }
     if (sum > 0 && sum * 100 <= (long long)N * 97) { packed = true; NR = (int)sum; Tmax = mx; }
   }
+  h->last_rows = NR;
+  h->last_rows_padded = N;
 
   if (B > h->lens_cap) {
     if (h->lens) HIPCHK(h, hipFree(h->lens));
@@ -1730,6 +1737,12 @@ int gam_set_rnnt_cluster(gam_handle* h, int workgroups_per_utterance) {
 }
 
 int gam_get_rnnt_cluster(gam_handle* h) { return h ? h->rnnt_cluster : -2; }
+
+int gam_last_encode_rows(gam_handle* h, int* rows_padded) {
+  if (!h) return -1;
+  if (rows_padded) *rows_padded = h->last_rows_padded;
+  return h->last_rows;
+}
 
 int gam_range_flag(gam_handle* h, int* flag_host, void* stream) {
   if (!h || !flag_host) return -1;

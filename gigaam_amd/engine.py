@@ -284,6 +284,12 @@ class HipEngine:
             wav_lengths = wav_lengths.tolist()
         return [self.feat_frames(int(n)) for n in wav_lengths]
 
+    def last_encode_rows(self) -> Tuple[int, int]:
+        """(token rows the layers of the last ``encode`` ran on, rows of the padded layout): equal unless that call packed its rows."""
+        pad = C.c_int(0)
+        rows = self.lib.gam_last_encode_rows(self._h, C.byref(pad))
+        return int(rows), int(pad.value)
+
     def encode(self, feat: Tensor, length: Tensor, n_layers_run: int = -1, want_tokens: bool = False, host_lengths=None):
         """``host_lengths``: the same feature lengths as ``length`` as host integers (``host_feat_lengths``).  With them a ragged batch's layers
         run on its valid frames only (gam_encode_varlen: packed rows); without them -- or for an equal-length batch -- on B x T'max rows."""

@@ -108,6 +108,10 @@ int gam_encode_ex(gam_handle* h, const float* feat, const int64_t* feat_len, int
 int gam_encode_varlen(gam_handle* h, const float* feat, const int64_t* feat_len, const int64_t* feat_len_host, int B, int64_t T,
                       float* encoded, int32_t* enc_len, int n_layers_run, float* tokens_out, void* stream);
 
+/* Token rows the Conformer layers of the LAST gam_encode / _ex / _varlen call of this handle ran on; *rows_padded (may be NULL) = B x Ta, what
+ * the padded layout takes.  Smaller than *rows_padded exactly when that call used packed rows. */
+int gam_last_encode_rows(gam_handle* h, int* rows_padded);
+
 /* CTCHead.forward: encoded f32 [B,d_model,T'] -> log_probs f32 [B,T',V]. */
 int gam_ctc_head(gam_handle* h, const float* encoded, int B, int64_t Tp, float* log_probs, void* stream);
 

@@ -15,9 +15,14 @@ pytestmark = pytest.mark.gpu
 def _engine(name, n_layers=2, **kw):
     from gigaam_amd import synth
     from gigaam_amd.engine import HipEngine, build_config
+    import os
     ck = synth.make_checkpoint(name, seed=3, n_layers=n_layers, **kw)
     cfg = ck["cfg"]
-    return HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], cfg.get("head")), ck["state_dict"], torch.device("cuda:0")), ck
+    os.environ["GAM_PACK"] = "2"      # (read by gam_create) packed rows also in the small-batch / hipGraph regime, where the product keeps padded rows
+    try:
+        return HipEngine(build_config(cfg["preprocessor"], cfg["encoder"], cfg.get("head")), ck["state_dict"], torch.device("cuda:0")), ck
+    finally:
+        del os.environ["GAM_PACK"]
 
 
 LENS_S = [3.0, 0.33, 2.01, 1.27, 2.56, 0.05, 2.999]     # incl. a 5-frame utterance and tile-edge lengths
@@ -36,7 +41,10 @@ def test_packed_rows_equal_padded_rows(name, mode):
     assert host == eng.host_feat_lengths(wlen)                      # the host formula is the device's
     for n_layers in (0, 1, -1):
         enc_p, elen_p, tok_p = eng.encode(feat, flen, n_layers_run=n_layers, want_tokens=True)                       # padded rows (no host lengths)
+        assert eng.last_encode_rows()[0] == eng.last_encode_rows()[1]
         enc_k, elen_k, tok_k = eng.encode(feat, flen, n_layers_run=n_layers, want_tokens=True, host_lengths=host)    # packed rows
+        rows, rows_pad = eng.last_encode_rows()
+        assert rows == int(elen_k.clamp(max=enc_k.shape[2]).sum()) < rows_pad
         assert torch.equal(elen_p, elen_k)
         worst = 0.0
         for b, n in enumerate(elen_p.cpu().tolist()):
@@ -55,14 +63,19 @@ def test_packed_rows_equal_padded_rows(name, mode):
 
 
 def test_packed_rows_bit_identical_without_splitk_and_faster_rows():
-    """32 ragged utterances (linspace(4 s, 8 s)): large enough that no GEMM is split along K, so packing changes nothing but which rows exist."""
+    """32 ragged utterances (linspace(4 s, 8 s)): large enough that no GEMM is split along K, so packing changes nothing but which rows exist.
+    Built with the product's defaults (no GAM_PACK): 6432 token rows are above the hipGraph regime, so the batch IS packed."""
     from gigaam_amd import synth
-    eng, _ = _engine("v2_ctc", n_layers=2)
+    from gigaam_amd.engine import HipEngine, build_config
+    ck = synth.make_checkpoint("v2_ctc", seed=3, n_layers=2)
+    eng = HipEngine(build_config(ck["cfg"]["preprocessor"], ck["cfg"]["encoder"], ck["cfg"].get("head")), ck["state_dict"], torch.device("cuda:0"))
     lens = [int(16000 * (4.0 + 4.0 * i / 31)) for i in range(32)]
     wav, wlen = synth.synth_audio(32, 8.0, seed=5, lengths=lens)
     feat, flen = eng.frontend(wav, wlen)
     enc_p, elen = eng.encode(feat, flen)
     enc_k, _ = eng.encode(feat, flen, host_lengths=flen.cpu().tolist())
+    rows, rows_pad = eng.last_encode_rows()
+    assert rows == int(elen.sum()) and rows < 0.8 * rows_pad           # packed by default at this size
     same = all(torch.equal(enc_p[b, :, :n], enc_k[b, :, :n]) for b, n in enumerate(elen.cpu().tolist()))
     worst = max(float((enc_p[b, :, :n] - enc_k[b, :, :n]).abs().max()) for b, n in enumerate(elen.cpu().tolist()))
     report("packed_vs_padded_b32", bit_identical=bool(same), max_abs=worst)
@@ -88,13 +101,22 @@ def test_model_api_packs_when_lengths_arrive_on_the_cpu():
     """model.transcribe_batch / launch_batch with CPU lengths (what load_audio + collate produce) == the same call with GPU lengths (padded rows)."""
     import gigaam_amd
     from gigaam_amd import synth
+    import os
     ck = synth.make_checkpoint("v2_rnnt", seed=1, n_layers=2)
-    model = gigaam_amd.model_from_checkpoint(ck, "cuda:0")
+    os.environ["GAM_PACK"] = "2"
+    try:
+        model = gigaam_amd.model_from_checkpoint(ck, "cuda:0")
+    finally:
+        del os.environ["GAM_PACK"]
     lens = [int(16000 * s) for s in (3.0, 1.1, 2.2, 0.4, 2.9, 1.7)]
     wav, wlen = synth.synth_audio(6, 3.0, seed=8, lengths=lens)
+    eng = model.encoder.engine
     got_cpu = model.transcribe_batch(wav, wlen)
+    r_cpu = eng.last_encode_rows()
     got_gpu = model.transcribe_batch(wav.cuda(), wlen.cuda())
+    r_gpu = eng.last_encode_rows()
     assert got_cpu == got_gpu
+    assert r_cpu[0] < r_cpu[1] and r_gpu[0] == r_gpu[1]      # CPU lengths: packed; GPU lengths: padded (no sync is made to fetch them)
 
 
 def test_packed_rows_with_an_utterance_of_zero_frames():
@@ -102,11 +124,12 @@ def test_packed_rows_with_an_utterance_of_zero_frames():
     gives that utterance no rows; every kernel must cope (cu[b] == cu[b + 1]) and the other utterances must be unaffected."""
     from gigaam_amd import synth
     eng, _ = _engine("v3_e2e_ctc")
-    lens = [32000, 160, 16000, 0, 24000]
+    lens = [32000, 160, 16000, 100, 24000]
     wav, wlen = synth.synth_audio(len(lens), 2.0, seed=4, lengths=lens)
     feat, flen = eng.frontend(wav, wlen)
     host = flen.cpu().tolist()
-    assert host[1] == 0 and host[3] == 0
+    assert host[1] <= 0 and host[3] <= 0           # (the reference's out_len floors: 100 samples -> -1, gigaam/preprocess.py:86-92; clamped downstream)
+    assert eng.host_feat_lengths(wlen)[3] == 0
     enc_p, elen = eng.encode(feat, flen)
     enc_k, elen_k = eng.encode(feat, flen, host_lengths=host)
     assert torch.equal(elen, elen_k) and elen.cpu().tolist()[1] == 0
