@@ -29,7 +29,7 @@ LENS_S = [3.0, 0.33, 2.01, 1.27, 2.56, 0.05, 2.999]     # incl. a 5-frame uttera
 
 
 @pytest.mark.parametrize("name", ["v2_ctc", "v3_e2e_ctc", "v1_ctc"])
-@pytest.mark.parametrize("mode", ["f16x3", "f32"])
+@pytest.mark.parametrize("mode", ["f16x3", "f32", "f16"])
 def test_packed_rows_equal_padded_rows(name, mode):
     from gigaam_amd import synth
     eng, _ = _engine(name)
@@ -53,11 +53,12 @@ def test_packed_rows_equal_padded_rows(name, mode):
             assert float(enc_k[b, :, n:].abs().max()) == 0.0 if n < enc_k.shape[2] else True     # zeros behind the last frame
             assert float(tok_k[b, n:].abs().max()) == 0.0 if n < tok_k.shape[1] else True
         report("packed_vs_padded", model=name, mode=mode, n_layers=n_layers, max_abs=worst)
-        assert worst <= 2e-5, (name, mode, n_layers, worst)
+        # (the opt-in fp16 speed mode rounds every GEMM operand to fp16: a last-bit difference of a split-K sum can move a rounding -- 5e-3)
+        assert worst <= (5e-3 if mode == "f16" else 2e-5), (name, mode, n_layers, worst)
     # an upper bound is enough ...
     enc_u, _ = eng.encode(feat, flen, host_lengths=[h + 7 for h in host])
     n0 = int(elen_p[0])
-    assert float((enc_u[0, :, :n0] - enc_p[0, :, :n0]).abs().max()) <= 2e-5
+    assert float((enc_u[0, :, :n0] - enc_p[0, :, :n0]).abs().max()) <= (5e-3 if mode == "f16" else 2e-5)
     torch.cuda.synchronize()
     assert eng.range_flag() is False
 
