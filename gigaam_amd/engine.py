@@ -94,9 +94,12 @@ class Decoded(tuple):
     nothing is known about a flag or an event (a plain blocking copy on the current stream)."""
 
     def __new__(cls, ids: Tensor, frames: Tensor, counts: Tensor, ext: Optional[Tensor] = None, event=None, stream=None,
-                dump: Optional[Tensor] = None, dump_count: Optional[Tensor] = None):
+                dump: Optional[Tensor] = None, dump_count: Optional[Tensor] = None, whole: Optional[Tensor] = None):
         self = tuple.__new__(cls, (ids, frames, counts) if dump is None else (ids, frames, counts, dump, dump_count))
         self.ext, self.event, self.stream = ext, event, stream
+        # ``whole`` (r06): ids | frames | ext are views of ONE i32 buffer [2 B cap + B + 1] -- a small decode (CTC: 128 KB at 32 x 20 s)
+        # then reaches the host in ONE blocking copy instead of three (counts first, then the used part of ids and of frames)
+        self.whole = whole
         return self
 
     ids = property(lambda self: self[0])
@@ -205,6 +208,8 @@ class HipEngine:
         return evt, st
 
     _collect_streams: Dict[int, "torch.cuda.Stream"] = {}
+    import os as _os
+    ONE_COPY_BYTES = int(_os.environ.get("GAM_ONE_COPY_BYTES", str(256 * 1024)))   # decodes up to this size reach the host in one copy (collect); 0: A/B switch
 
     @classmethod
     def _collect_stream(cls, device: torch.device) -> "torch.cuda.Stream":
@@ -228,11 +233,27 @@ class HipEngine:
         flag accumulated up to this decode, one for the used part of ids / frames, both on a side stream that waits for the
         decode's own completion event only.  Three bare tensors (ids, frames, counts) are accepted for callers that built them
         some other way: a plain blocking copy on the current stream, flag unknown (False)."""
+        whole = None
         if isinstance(dec, Decoded):
             ids, frames, counts, ext, evt = dec[0], dec[1], dec[2], dec.ext, dec.event
+            whole = getattr(dec, "whole", None)
         else:
             ids, ext, evt = dec, None, None
         src = ext if ext is not None else counts
+        if whole is not None and evt is not None and whole.is_cuda and whole.numel() * 4 <= HipEngine.ONE_COPY_BYTES:
+            # one blocking D2H of the whole decode (a second and third round trip cost more than the unused tail of ids / frames)
+            side = HipEngine._collect_stream(whole.device)
+            with torch.cuda.stream(side):
+                side.wait_event(evt)
+                host = whole.cpu()
+            whole.record_stream(side)
+            b, cap = ids.shape
+            n = host[2 * b * cap:].tolist()
+            flag = HipEngine._flag_of(n.pop())
+            if n and min(n) < 0:
+                raise GigaAMHipError("decode left an utterance undecoded (counts = -1)")
+            ids_h, fr_h = host[: b * cap].view(b, cap), host[b * cap: 2 * b * cap].view(b, cap)
+            return [(ids_h[i, :c].tolist(), fr_h[i, :c].tolist()) for i, c in enumerate(n)], flag
         if evt is not None and ids.is_cuda:
             side = HipEngine._collect_stream(ids.device)
             with torch.cuda.stream(side):
@@ -344,15 +365,15 @@ class HipEngine:
         encoded = self._dev(encoded, torch.float32)
         enc_len = self._dev(enc_len, torch.int32)
         b, _, tp = encoded.shape
-        ids = torch.empty((b, tp), dtype=torch.int32, device=self.device)
-        frames = torch.empty((b, tp), dtype=torch.int32, device=self.device)
-        counts, ext = self._counts_with_flag(b)
+        whole = torch.empty((2 * b * tp + b + 1,), dtype=torch.int32, device=self.device)     # ids | frames | counts + flag word
+        ids, frames, ext = whole[: b * tp].view(b, tp), whole[b * tp: 2 * b * tp].view(b, tp), whole[2 * b * tp:]
+        counts = ext[:b]
         with torch.cuda.device(self.device):
             rc = self.lib.gam_ctc_greedy(self._h, _ptr(encoded), _ptr(enc_len), b, tp, _ptr(ids), _ptr(frames),
                                          _ptr(counts), self._stream())
             self._check(rc, "gam_ctc_greedy")
             evt, st = self._fetch_flag(ext)
-        return Decoded(ids, frames, counts, ext, evt, st)
+        return Decoded(ids, frames, counts, ext, evt, st, whole=whole)
 
     def set_rnnt_cluster(self, n: int) -> None:
         """Workgroups per utterance of the cluster decode kernel (gam_set_rnnt_cluster): -1 auto, 0 one-workgroup kernel, 1..8."""
