@@ -1,5 +1,10 @@
 #!/bin/bash
 # r06 GPU sessions (one stage per gpurun call):  gpurun --timeout 1500 -- 'bash tools/gpu_r06.sh <stage>'
+# Provenance of profiles/r06_* (index: profiles/r06_INDEX.txt).  Stages s1-s5 / s11 use VARIANT builds of the library that are not kept in the
+# tree; each is the build command of gigaam_amd/build.py (hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC gigaam_amd/csrc/gam_api.hip -o ...)
+# with:  libgigaam_hip.so (s1-s3: r05's flags, i.e. WITHOUT -fno-slp-vectorize)   _noslp: -fno-slp-vectorize   _audit: -DGAM_RC_AUDIT=1
+#        _audit_noslp: both   _pv2: -fno-slp-vectorize -DGAM_ATT_PV_TERMS=2   _nt / _sc1: -DGAM_RC_NOL1=1 / 2 (weight loads past the L1; the switch
+#        was removed again after s1 refuted it).  The canaries build from tools/*.hip with the command in their first comment block.
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd /root/repo
 R=$PWD
 STAGE=${1:-s1}
