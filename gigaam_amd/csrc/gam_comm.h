@@ -40,10 +40,15 @@ static inline Api* api() {   // resolved once per process (thread-safe)
 }
 static inline void load(Api& a) {
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) {
-    a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  for (const char* n : names) {      // first the instance the process already holds (inside torch: torch's own RCCL), whatever file it came from
+    a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
     if (a.lib) break;
   }
+  if (!a.lib)
+    for (const char* n : names) {
+      a.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (a.lib) break;
+    }
   if (!a.lib) { a.err = std::string("cannot load librccl: ") + dlerror(); return; }
 #define GAM_RCCL_SYM(field, name)                                         \
   a.field = reinterpret_cast<decltype(a.field)>(dlsym(a.lib, name));     \
