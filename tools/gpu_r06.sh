@@ -112,5 +112,11 @@ print('$lib:', d['ms_per_step'], 'ms', d['value'], 'x attn', d['kernel_classes_m
   ( GIGAAM_HIP_LIB=$R/gigaam_amd/libgigaam_hip_pv2.so timeout 1500 python -m pytest tests -q -m gpu ) > $OUT/pytest_pv2.log 2>&1; echo "pytest pv2 rc=$?"
   grep -a "passed\|failed" $OUT/pytest_pv2.log | tail -3 | tee -a $OUT/pv2.txt; grep -a "^FAILED" $OUT/pytest_pv2.log | head -40 | tee -a $OUT/pv2.txt
   ;;
+s13)  # the one-switch reproducer, long: the same sources built WITH hipcc's SLP packing (libgigaam_hip_slp.so: 100+ v_pk_fma_f32 op_sel:[0,1,0]) and the
+      # product library, same box, same script, no whole-CU claim
+  repro slp     libgigaam_hip_slp.so GAM_RNNT_EXCLUSIVE=0 timeout 600 python tools/coresidency_repro.py 1,2 5000 gemm640
+  repro product libgigaam_hip.so     GAM_RNNT_EXCLUSIVE=0 timeout 900 python tools/coresidency_repro.py 1,2 20000 gemm640
+  repro slp2    libgigaam_hip_slp.so GAM_RNNT_EXCLUSIVE=0 timeout 600 python tools/coresidency_repro.py 1 5000 gemm640
+  ;;
 *) echo "unknown stage $STAGE"; exit 2;;
 esac
