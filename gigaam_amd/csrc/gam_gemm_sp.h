@@ -550,9 +550,21 @@ static inline double gam_gemm_sp_model(int M, int N, int K, int a_mode, int t, i
     rounds = (double)((wgs + ncu - 1) / ncu);
   } else {
     const bool shared = wgs > ncu;                // two 4-wave workgroups on one CU
-    t_kt = (0.256 * t + 0.142) * (shared ? 1.82 : 1.0);
-    t_fix = (S > 1 ? 4.9 : 14.1) * (shared ? 0.73 : 1.0);
+    const double tk_u = 0.256 * t + 0.142, tf_u = S > 1 ? 4.9 : 14.1;
+    t_kt = tk_u * (shared ? 1.82 : 1.0);
+    t_fix = tf_u * (shared ? 0.73 : 1.0);
     rounds = (double)((wgs + (shared ? 2 : 1) * ncu - 1) / ((shared ? 2 : 1) * ncu));
+    // r06: a last round of at most ONE workgroup per CU runs unshared (756 tiles = one shared round of 512 + 244 alone): counted as a
+    // whole shared round it made the three-stage class look better than it is -- the model's three worst picks (M = 8032 / N = 2304,
+    // M = 12 017 / N = 1536, M = 5681 / N = 3072: 12-14 % slower than the best measured) were this; mean regret of the plan over the 36
+    // shapes of profiles/r06_gemm_sweep_*.txt 1.4 % -> 0.3 %, worst 14 % -> 2 %; no pick changes at the headline's row count.
+    const long cap2 = 2L * ncu, rem = wgs % cap2;
+    if (shared && wgs > cap2 && rem != 0 && rem <= ncu) {
+      (void)a_mode;
+      double us2 = (double)(wgs / cap2) * (nkt * t_kt + t_fix) + (nkt * tk_u + tf_u);
+      if (S > 1) us2 += 7.1 + (double)(S + 2) * M * N * 4.0 / 3.87e6;
+      return us2;
+    }
   }
   (void)a_mode;
   double us = rounds * (nkt * t_kt + t_fix);
