@@ -414,7 +414,10 @@ class HipEngine:
         cap = tp * max_symbols
         main = torch.cuda.current_stream(self.device)
         side = self._decode_side_stream() if overlap else None
-        counts, ext = self._counts_with_flag(b)
+        # ids | frames | counts + flag word as views of ONE buffer (allocated on the launch stream): a small decode reaches the host in one copy
+        whole = torch.empty((2 * b * cap + b + 1,), dtype=torch.int32, device=self.device)
+        ext = whole[2 * b * cap:]
+        counts = ext[:b]
         if overlap:
             with torch.cuda.device(self.device):
                 self._fetch_flag(ext)            # on the launch stream: this batch's own flag (its event is not the decode's)
@@ -423,8 +426,7 @@ class HipEngine:
             self._check(self.lib.gam_set_rnnt_cluster(self._h, c_side), "gam_set_rnnt_cluster")     # (for this call only: restored below)
         try:
             with torch.cuda.stream(side) if overlap else torch.cuda.device(self.device):
-                ids = torch.empty((b, cap), dtype=torch.int32, device=self.device)
-                frames = torch.empty((b, cap), dtype=torch.int32, device=self.device)
+                ids, frames = whole[: b * cap].view(b, cap), whole[b * cap: 2 * b * cap].view(b, cap)
                 dump = dcount = None
                 if dump_cap > 0:
                     dump = torch.zeros((b, dump_cap, self.cfg.num_classes), dtype=torch.float32, device=self.device)
@@ -436,14 +438,14 @@ class HipEngine:
                     st = torch.cuda.current_stream(self.device)
                     evt = torch.cuda.Event()
                     evt.record(st)
-                    for t in (encoded, enc_len, ext):      # allocated on the launch stream, last used on the side stream
+                    for t in (encoded, enc_len, whole):    # allocated on the launch stream, last used on the side stream
                         t.record_stream(st)
                 else:
                     evt, st = self._fetch_flag(ext)
         finally:
             if overlap:
                 self._check(self.lib.gam_set_rnnt_cluster(self._h, self._rnnt_cluster_user), "gam_set_rnnt_cluster")
-        return Decoded(ids, frames, counts, ext, evt, st, dump, dcount)
+        return Decoded(ids, frames, counts, ext, evt, st, dump, dcount, whole=whole)
 
     def rnnt_predict(self, labels: Optional[Tensor], state: Optional[Tuple[Tensor, Tensor]], batch_size: int = 1):
         """One predictor step (reference RNNTDecoder.predict, gigaam/decoder.py:85-102): labels i [B] or None (zero input),
