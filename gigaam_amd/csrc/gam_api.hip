@@ -1381,6 +1381,7 @@ static int ctc_logits(gam_handle* h, const float* encoded, int B, int64_t Tp, hi
 int gam_ctc_head(gam_handle* h, const float* encoded, int B, int64_t Tp, float* log_probs, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!h) return -1;
+  HIPCHK(h, hipSetDevice(h->device));     // (before the scope: its event belongs to the handle's device)
   DecodeScope ds(h, s);
   if (int r = ctc_logits(h, encoded, B, Tp, s)) return r;
   const int V = h->cfg.num_classes, rows = (int)(B * Tp);
@@ -1394,6 +1395,7 @@ int gam_ctc_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len, 
                    int32_t* frames, int32_t* counts, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!h) return -1;
+  HIPCHK(h, hipSetDevice(h->device));     // (before the scope: its event belongs to the handle's device)
   DecodeScope ds(h, s);
   if (int r = ctc_logits(h, encoded, B, Tp, s)) return r;
   const int V = h->cfg.num_classes;
