@@ -112,6 +112,20 @@ print('$lib:', d['ms_per_step'], 'ms', d['value'], 'x attn', d['kernel_classes_m
   ( GIGAAM_HIP_LIB=$R/gigaam_amd/libgigaam_hip_pv2.so timeout 1500 python -m pytest tests -q -m gpu ) > $OUT/pytest_pv2.log 2>&1; echo "pytest pv2 rc=$?"
   grep -a "passed\|failed" $OUT/pytest_pv2.log | tail -3 | tee -a $OUT/pv2.txt; grep -a "^FAILED" $OUT/pytest_pv2.log | head -40 | tee -a $OUT/pv2.txt
   ;;
+s14)  # EXPERIMENT (experiments/r06_attn_longest_first.patch, _noorder = the committed library): packed rows: attention workgroups dispatched longest utterance first (order[] of gam_pack_index_kernel) vs batch order, same box, interleaved
+  ( timeout 900 python -m pytest tests/test_hip_varlen.py -q -x ) > $OUT/varlen.log 2>&1; echo "varlen rc=$?"; tail -3 $OUT/varlen.log
+  ( timeout 1200 python -m pytest tests -q -m gpu -x -k "ragged or live or fullsize or model_api" ) > $OUT/ragged.log 2>&1; echo "ragged rc=$?"; tail -4 $OUT/ragged.log
+  C="--cpu-utts 0 --steps 12 --warmup 3 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power"
+  for rep in 1 2 3; do
+    for lib in libgigaam_hip_noorder.so libgigaam_hip.so; do
+      for extra in "--config 2 --ragged" "--config 3 --ragged"; do
+        ( GIGAAM_HIP_LIB=$R/gigaam_amd/$lib timeout 500 python bench.py $C $extra ) 2>> $OUT/ab.err | grep -a '^{' | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('$lib $extra:', d['ms_per_step'], 'ms', d['value'], 'x', d.get('kernel_classes_ms_per_step'))" | tee -a $OUT/ab.txt
+      done
+    done
+  done
+  ;;
 s13)  # the one-switch reproducer, long: the same sources built WITH hipcc's SLP packing (libgigaam_hip_slp.so: 100+ v_pk_fma_f32 op_sel:[0,1,0]) and the
       # product library, same box, same script, no whole-CU claim
   repro slp     libgigaam_hip_slp.so GAM_RNNT_EXCLUSIVE=0 timeout 600 python tools/coresidency_repro.py 1,2 5000 gemm640
