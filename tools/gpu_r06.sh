@@ -126,6 +126,18 @@ d = json.loads(sys.stdin.read()); print('$lib $extra:', d['ms_per_step'], 'ms', 
     done
   done
   ;;
+s15)  # EXPERIMENT (engine._decode_side_stream read GAM_SIDE_STREAM_PRIORITY for this run only): the overlapped RNN-T decode's side stream at normal vs high priority (a high-priority stream has its own hardware-queue pool)
+  C="--cpu-utts 0 --steps 12 --warmup 3 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power --no-profile"
+  for rep in 1 2 3; do
+    for pr in 0 -1; do
+      for extra in "--config 3" "--config 3 --ragged" "--config 4 --steps 4"; do
+        ( GAM_SIDE_STREAM_PRIORITY=$pr timeout 500 python bench.py $C $extra ) 2>> $OUT/ab.err | grep -a '^{' | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('priority $pr $extra:', d['ms_per_step'], 'ms', d['value'], 'x')" | tee -a $OUT/ab.txt
+      done
+    done
+  done
+  ;;
 s13)  # the one-switch reproducer, long: the same sources built WITH hipcc's SLP packing (libgigaam_hip_slp.so: 100+ v_pk_fma_f32 op_sel:[0,1,0]) and the
       # product library, same box, same script, no whole-CU claim
   repro slp     libgigaam_hip_slp.so GAM_RNNT_EXCLUSIVE=0 timeout 600 python tools/coresidency_repro.py 1,2 5000 gemm640
