@@ -142,3 +142,41 @@ def test_packed_rows_with_an_utterance_of_zero_frames():
     from gigaam_amd.engine import HipEngine
     rows, flag = HipEngine.collect(dec)
     assert rows[1] == ([], []) and rows[3] == ([], []) and not flag
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_packed_rows_on_random_batches(seed):
+    """Seeded random batch sizes and lengths (a third of the utterances very short, some equal, the longest anywhere in the batch), rotary and
+    rel-pos attention, BatchNorm and LayerNorm conv modules: packed == padded on every valid frame, CTC ids equal."""
+    import random
+    from gigaam_amd import synth
+    from gigaam_amd.engine import HipEngine
+    rng = random.Random(1234 + seed)
+    name = ["v2_ctc", "v3_e2e_ctc", "v1_ctc", "v2_ctc"][seed]
+    eng, _ = _engine(name)
+    for _ in range(3):
+        b = rng.choice([2, 3, 5, 9, 17, 33])
+        tmax = rng.choice([1.0, 2.5, 4.0])
+        lens = []
+        for _ in range(b):
+            r = rng.random()
+            s = rng.uniform(0.03, 0.2) if r < 0.33 else (tmax if r > 0.9 else rng.uniform(0.2, tmax))
+            lens.append(max(400, int(16000 * s)))
+        if len(set(lens)) == 1:
+            lens[0] = max(400, lens[0] // 2)
+        wav, wlen = synth.synth_audio(b, max(lens) / 16000.0, seed=seed, lengths=lens)
+        feat, flen = eng.frontend(wav, wlen)
+        host = flen.cpu().tolist()
+        enc_p, elen = eng.encode(feat, flen)
+        ids_p, _ = HipEngine.collect(eng.ctc_greedy(enc_p, elen))
+        enc_k, elen_k = eng.encode(feat, flen, host_lengths=host)
+        rows, rows_pad = eng.last_encode_rows()
+        ids_k, flag = HipEngine.collect(eng.ctc_greedy(enc_k, elen_k))
+        assert torch.equal(elen, elen_k) and not flag
+        n_valid = int(elen.clamp(min=0, max=enc_p.shape[2]).sum())
+        assert rows == n_valid or rows == rows_pad        # (under 3 % padding the batch keeps padded rows)
+        worst = max([float((enc_p[i, :, :n] - enc_k[i, :, :n]).abs().max()) for i, n in enumerate(elen.cpu().tolist()) if n > 0] or [0.0])
+        report("packed_vs_padded_random", model=name, batch=b, rows=rows, rows_padded=rows_pad, max_abs=worst)
+        assert worst <= 2e-5, (name, b, lens, worst)
+        assert ids_p == ids_k
+        assert bool(torch.isfinite(enc_k).all())
