@@ -138,6 +138,11 @@ d = json.loads(sys.stdin.read()); print('priority $pr $extra:', d['ms_per_step']
     done
   done
   ;;
+s16)  # EXPERIMENT (needs profiles/experiments/r06_half_tiles.patch applied: it adds the kernels, gam_tune_sp_half, the test file and --half): half tiles (96 / 160 / 224 x 256): kernel tests, then the calibration sweep at packed-row and standard row counts
+  ( timeout 900 python -m pytest tests/test_hip_half_tiles.py tests/test_hip_varlen.py -q -x ) > $OUT/tests.log 2>&1; echo "tests rc=$?"; tail -5 $OUT/tests.log
+  ( timeout 1500 python tools/smallm_sweep.py --calib --stages --half --rows=12017,5681,16064,8032,4016,2008,6432,10000,14000 ) > $OUT/sweep.txt 2> $OUT/sweep.err; echo "sweep rc=$?"; tail -3 $OUT/sweep.err
+  cp gpurun_out/smallm_sweep.json $OUT/sweep.json 2>/dev/null
+  ;;
 s13)  # the one-switch reproducer, long: the same sources built WITH hipcc's SLP packing (libgigaam_hip_slp.so: 100+ v_pk_fma_f32 op_sel:[0,1,0]) and the
       # product library, same box, same script, no whole-CU claim
   repro slp     libgigaam_hip_slp.so GAM_RNNT_EXCLUSIVE=0 timeout 600 python tools/coresidency_repro.py 1,2 5000 gemm640
