@@ -528,6 +528,8 @@ def main():
                     "encoder of batch n+1 (small clusters; configs 3 / 4), 0 = in front of it on the launch stream (full-size clusters)")
     ap.add_argument("--rnnt-side-cus", type=int, default=0, help="compute units an overlapped RNN-T decode may hold (cluster size = this / utterance "
                     "slots); 0 = the engine's choice (96 for a char vocabulary, 160 for a SentencePiece one)")
+    ap.add_argument("--pre-streams", type=int, default=0, help="debug: take this many streams from torch's pool before the model exists, as an "
+                    "application with streams of its own would (which hardware queue a later stream shares depends on it: tools/queue_probe.py)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--no-power", action="store_true", help="skip the board power / shader clock sampling leg")
     ap.add_argument("--no-f32-leg", action="store_true", help="skip the exact-fp32 re-timing (roofline_f32_exact)")
@@ -609,6 +611,12 @@ def main():
 
     import gigaam_amd
     from gigaam_amd import synth, workloads
+
+    _pre = []
+    for _ in range(args.pre_streams):
+        _pre.append(torch.cuda.Stream(dev))
+        with torch.cuda.stream(_pre[-1]):
+            torch.zeros(8, device=dev).add_(1)
 
     cfgno = args.config
     model_name = args.model or {1: "v2_ctc", 2: "v2_ctc", 3: "v2_rnnt", 4: "v3_e2e_rnnt", 5: "v2_ctc"}[cfgno]
@@ -802,29 +810,41 @@ def main():
     PROF_EVERY = 4
     n_prof_steps = (args.steps + PROF_EVERY - 1) // PROF_EVERY
 
+    timed_diag = {}
+
     def timed(k_steps, profile):
         barrier_sync()
         if profile:
             eng.profile_enable(0)      # reset the collectors
+        allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
         t0 = time.perf_counter()
         out_ = None
+        marks = []
         for i in range(k_steps):
             if profile:
                 eng.profile_level(2 if i % PROF_EVERY == 0 else 0)
             o = step()
+            marks.append(time.perf_counter())
             out_ = o if o is not None else out_
         o = drain()
         out_ = o if o is not None else out_
         barrier_sync()
+        t1 = time.perf_counter()
         if profile:
             eng.profile_level(0)
-        return max_over_ranks(time.perf_counter() - t0), out_
+        # diagnostics of the timed region (not part of the contract): hipMalloc calls of torch's caching allocator inside it (each one
+        # synchronises the device: a pipelined step that still grows its pool is not in steady state) and the host-side time of every step
+        timed_diag.update({"device_allocs": int(torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0),
+                           "host_ms_per_step": [round((b - a) * 1e3, 2) for a, b in zip([t0] + marks[:-1], marks)],
+                           "drain_ms": round((t1 - marks[-1]) * 1e3, 2) if marks else None})
+        return max_over_ranks(t1 - t0), out_
 
     for _ in range(args.warmup):
         step()
     drain()
     do_prof = not args.no_profile
     dt, out = timed(args.steps, do_prof)
+    timed_region = dict(timed_diag)
     prof = prof_all = None
     if do_prof:
         prof = eng.profile_read()
@@ -970,6 +990,7 @@ def main():
         line["config"]["token_rows_last_batch"] = {"run": r_run, "padded_layout": r_pad, "packed": bool(r_run < r_pad)}
     except Exception:   # noqa: BLE001
         pass
+    line["timed_region"] = timed_region
     line["gather_path"] = gather_name        # (top level: a silent fall-back to torch.distributed on the 8-GPU node must be visible)
     if cfgno == 5:
         line["config"]["dealing"] = dealing

@@ -207,17 +207,29 @@ class HipEngine:
         evt.record(st)
         return evt, st
 
-    _collect_streams: Dict[int, "torch.cuda.Stream"] = {}
+    _aux_streams: Dict[int, Tuple["torch.cuda.Stream", "torch.cuda.Stream", "torch.cuda.Stream"]] = {}
     import os as _os
     ONE_COPY_BYTES = int(_os.environ.get("GAM_ONE_COPY_BYTES", str(256 * 1024)))   # decodes up to this size reach the host in one copy (collect); 0: A/B switch
 
     @classmethod
-    def _collect_stream(cls, device: torch.device) -> "torch.cuda.Stream":
+    def aux_streams(cls, device: torch.device) -> Tuple["torch.cuda.Stream", "torch.cuda.Stream", "torch.cuda.Stream"]:
+        """(decode side stream, collect stream, host-to-device copy stream) of a device: three HIGH-priority streams taken from torch's pool in
+        one go.  Why (tools/queue_probe.py, profiles/r06_queue_probe.txt): HIP maps streams onto four hardware queues per priority level, round
+        robin in creation order, and two streams on one queue SERIALISE -- one normal-priority stream in four lands on the null stream's queue,
+        where an "overlapped" decode, the ids' D2H copy or the next batch's H2D copy silently queues behind the encoder it was meant to run
+        beside (both / one = 2.00 instead of 1.00).  High-priority streams have their own four queues (never the launch stream's, whatever
+        the caller created before), and three taken consecutively are on three different ones.  Same-box A/B of the priority alone: neutral."""
         key = device.index if device.index is not None else torch.cuda.current_device()
-        st = cls._collect_streams.get(key)
+        st = cls._aux_streams.get(key)
         if st is None:
-            st = cls._collect_streams[key] = torch.cuda.Stream(device)
+            import os
+            prio = int(os.environ.get("GAM_AUX_STREAM_PRIORITY", "-1"))     # (0: the A/B switch of profiles/r06_queue_probe.txt)
+            st = cls._aux_streams[key] = tuple(torch.cuda.Stream(device, priority=prio) for _ in range(3))
         return st
+
+    @classmethod
+    def _collect_stream(cls, device: torch.device) -> "torch.cuda.Stream":
+        return cls.aux_streams(device)[1]
 
     @staticmethod
     def _flag_of(word: int) -> bool:
@@ -381,10 +393,7 @@ class HipEngine:
         self._rnnt_cluster_user = int(n)
 
     def _decode_side_stream(self) -> "torch.cuda.Stream":
-        st = getattr(self, "_side_stream", None)
-        if st is None:
-            st = self._side_stream = torch.cuda.Stream(self.device)
-        return st
+        return self.aux_streams(self.device)[0]      # (shared by the engines of a device: see aux_streams)
 
     @staticmethod
     def side_cluster(b: int, side_cus: int) -> int:

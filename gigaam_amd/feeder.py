@@ -69,7 +69,8 @@ class BatchFeeder:
         self.segments = segments
         self.batch_size = batch_size
         self.device = torch.device(device)
-        self._copy_stream = torch.cuda.Stream(self.device)
+        from .engine import HipEngine
+        self._copy_stream = HipEngine.aux_streams(self.device)[2]     # (a stream that cannot share a hardware queue with the consumer's)
         max_b = min(batch_size, max(1, len(segments)))
         max_l = max((int(s.shape[-1]) for s in segments), default=1)
         self._pin = [torch.empty((max_b * max_l,), dtype=torch.float32).pin_memory() for _ in range(2)]

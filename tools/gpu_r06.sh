@@ -143,6 +143,33 @@ s16)  # EXPERIMENT (needs profiles/experiments/r06_half_tiles.patch applied: it 
   ( timeout 1500 python tools/smallm_sweep.py --calib --stages --half --rows=12017,5681,16064,8032,4016,2008,6432,10000,14000 ) > $OUT/sweep.txt 2> $OUT/sweep.err; echo "sweep rc=$?"; tail -3 $OUT/sweep.err
   cp gpurun_out/smallm_sweep.json $OUT/sweep.json 2>/dev/null
   ;;
+s17)  # config 4 (packed rows + overlapped decode): run-to-run / box-to-box spread (final3 visit: 98.96 ms where final2 had 89.1), hardware-queue count, CUs held by the side decode
+  C="--config 4 --cpu-utts 0 --steps 4 --warmup 2 --no-f32-leg --no-h2d-leg --no-f16-leg --no-power --no-profile"
+  run() { ( env "$@" timeout 500 python bench.py $C $X ) 2>> $OUT/ab.err | grep -a '^{' | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('$* $X:', d['ms_per_step'], 'ms', d['value'], 'x')" | tee -a $OUT/ab.txt; }
+  for rep in 1 2; do
+    X="" run A=1
+    X="" run GPU_MAX_HW_QUEUES=8
+    X="--rnnt-side-cus 96" run A=1
+    X="--rnnt-side-cus 224" run A=1
+    X="--rnnt-overlap 0" run A=1
+    X="--no-pack" run A=1
+  done
+  ;;
+s20)  # auxiliary streams (decode side / collect / H2D copy) at normal vs high priority when the application took k streams from torch's pool first
+  ( timeout 300 python tools/queue_probe.py ) > $OUT/queue.txt 2> $OUT/queue.err; grep -c "= 2.00" $OUT/queue.txt
+  C="--cpu-utts 0 --steps 8 --warmup 2 --no-f32-leg --no-f16-leg --no-power --no-profile"
+  for k in 0 1 2 3 4; do
+    for pr in 0 -1; do
+      for extra in "--config 3 --no-h2d-leg" "--config 4 --steps 4 --no-h2d-leg" "--config 5 --steps 3 --no-h2d-leg"; do
+        ( GAM_AUX_STREAM_PRIORITY=$pr timeout 500 python bench.py $C $extra --pre-streams $k ) 2>> $OUT/ab.err | grep -a '^{' | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('pre-streams $k priority $pr $extra:', d['ms_per_step'], 'ms', d['value'], 'x')" | tee -a $OUT/ab.txt
+      done
+    done
+  done
+  ;;
 s13)  # the one-switch reproducer, long: the same sources built WITH hipcc's SLP packing (libgigaam_hip_slp.so: 100+ v_pk_fma_f32 op_sel:[0,1,0]) and the
       # product library, same box, same script, no whole-CU claim
   repro slp     libgigaam_hip_slp.so GAM_RNNT_EXCLUSIVE=0 timeout 600 python tools/coresidency_repro.py 1,2 5000 gemm640
