@@ -137,7 +137,11 @@ int gam_rnnt_greedy(gam_handle* h, const float* encoded, const int32_t* enc_len,
  * Decode-class calls of one handle (gam_ctc_head / gam_ctc_greedy / gam_rnnt_greedy / gam_rnnt_joint) share one set of
  * scratch buffers: the library orders them itself -- a call on a stream other than the previous decode-class call's first
  * waits for that call's completion event (r06) -- so the caller may put them on any streams; they never run concurrently
- * with each other.  (Environment GAM_RNNT_CLUSTER sets the initial value, clamped to -1..8.) */
+ * with each other.  (Environment GAM_RNNT_CLUSTER sets the initial value, clamped to -1..8.)
+ * Which stream to hand over for a decode that is to run BESIDE an encoder (r06, tools/queue_probe.py): HIP maps the streams of one
+ * priority level onto four hardware queues in creation order and two streams on one queue serialise -- one stream in four created with
+ * hipStreamCreate shares the null stream's queue.  Create the side stream with hipStreamCreateWithPriority at the HIGH priority (its level
+ * has its own queues); the Python layer does (engine.HipEngine.aux_streams). */
 int gam_set_rnnt_cluster(gam_handle* h, int workgroups_per_utterance);
 /* The setting in force (-1 auto, 0 .. 8); -2 for a NULL handle. */
 int gam_get_rnnt_cluster(gam_handle* h);
