@@ -334,3 +334,36 @@ def test_decodes_on_different_streams_are_ordered_by_the_library():
         assert HipEngine.collect(big)[0] == want_big, rep
 
 
+
+
+def test_auxiliary_streams_never_share_the_launch_streams_hardware_queue():
+    """HIP maps the streams of one priority level onto four hardware queues in creation order, and two streams on one queue serialise: one
+    normal-priority stream in four shares the NULL stream's queue (tools/queue_probe.py, profiles/r06_queue_probe.txt) -- an "overlapped" decode
+    on such a stream silently runs behind the encoder.  The engine's decode / collect / copy streams are high-priority streams taken together:
+    whatever the application created before, a spin kernel on each of them runs BESIDE one on the launch stream and beside each other."""
+    import time
+    dev = torch.device("cuda:0")
+    mine = [torch.cuda.Stream(dev) for _ in range(5)]          # an application with streams of its own
+    for s in mine:
+        with torch.cuda.stream(s):
+            torch.zeros(8, device=dev).add_(1)
+    from gigaam_amd.engine import HipEngine
+    aux = HipEngine.aux_streams(dev)
+    assert len(aux) == 3 and len({s.cuda_stream for s in aux}) == 3 and all(s.priority == -1 for s in aux)
+    cyc = 10_000_000
+
+    def run(streams):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in streams:
+            with torch.cuda.stream(s):
+                torch.cuda._sleep(cyc)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    for launch in [torch.cuda.default_stream(dev)] + mine:
+        run([launch]); run([launch, *aux])
+        one = min(run([launch]) for _ in range(3))
+        allfour = min(run([launch, *aux]) for _ in range(3))
+        report("aux_streams_beside_launch_stream", ratio=allfour / one)
+        assert allfour < 1.5 * one, (allfour, one)      # serialised: 2x .. 4x
