@@ -180,3 +180,23 @@ def test_packed_rows_on_random_batches(seed):
         assert worst <= 2e-5, (name, b, lens, worst)
         assert ids_p == ids_k
         assert bool(torch.isfinite(enc_k).all())
+
+
+def test_batches_beyond_the_pack_index_capacity_keep_padded_rows():
+    """The pack index is built by one workgroup with a 1024-entry prefix table: 1024 utterances pack, 1030 keep the padded layout -- same result."""
+    from gigaam_amd import synth
+    eng, _ = _engine("v2_ctc")
+    for b in (1024, 1030):
+        lens = [int(16000 * (0.25 + 0.35 * ((7 * i + 3) % 11) / 10)) for i in range(b)]
+        wav, wlen = synth.synth_audio(b, max(lens) / 16000.0, seed=9, lengths=lens)
+        feat, flen = eng.frontend(wav, wlen)
+        enc_p, elen = eng.encode(feat, flen)
+        enc_k, elen_k = eng.encode(feat, flen, host_lengths=flen.cpu().tolist())
+        rows, rows_pad = eng.last_encode_rows()
+        assert (rows < rows_pad) == (b <= 1024), (b, rows, rows_pad)
+        assert torch.equal(elen, elen_k)
+        n = elen.cpu().tolist()
+        worst = max(float((enc_p[i, :, :n[i]] - enc_k[i, :, :n[i]]).abs().max()) for i in range(0, b, 37))
+        assert worst <= 2e-5, (b, worst)
+        assert bool(torch.isfinite(enc_k).all())
+    assert eng.range_flag() is False
