@@ -13,7 +13,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 
 import gigaam_amd  # noqa: E402
 from gigaam_amd import synth, workloads  # noqa: E402

@@ -1,4 +1,4 @@
-"""r06: do two HIP streams always get two hardware queues?  (No: tools/two_chain_probe.py found two torch streams on ONE queue, where their
+"""r06: do two HIP streams always get two hardware queues?  (No: profiles/experiments/r06_session_scripts/two_chain_probe.py found two torch streams on ONE queue, where their
 kernels serialise.  The overlapped RNN-T decode -- engine.rnnt_greedy(overlap=True) -- relies on its side stream running BESIDE the launch stream.)
 
 For K = 0 .. 11 streams created (and used once) before it, a side stream of normal / high priority runs a one-thread spin kernel
