@@ -806,8 +806,9 @@ def main():
     # ---- timing: W warm-up steps, then EXACTLY K steps between barrier + synchronize pairs; max over ranks
     # Per-launch HIP-event pairs around the GEMM family INSIDE the timed region (the roofline's launch durations), on every
     # PROF_EVERY-th timed step: an event pair costs ~3 us on this runtime (it drains the queue between kernels), 0.9 ms of a
-    # fully instrumented 33 ms step and 1 ms of an 8 ms one -- sampling keeps the measurement from moving what it measures.
-    PROF_EVERY = 4
+    # fully instrumented 33 ms step and 1 ms of an 8 ms one -- sampling keeps the measurement from moving what it measures (r06: every 10th
+    # step instead of every 4th -- timed_region.host_ms_per_step showed the instrumented steps 1.0 ms long; 2 x 130 launches are sample enough).
+    PROF_EVERY = 10
     n_prof_steps = (args.steps + PROF_EVERY - 1) // PROF_EVERY
 
     timed_diag = {}
@@ -1040,7 +1041,7 @@ def main():
             "launches_per_step": n // max(1, n_prof_steps), "avg_launch_ms": round(ms / max(1, n), 4),
             "algorithmic_gflop_per_step": round(flop / n_prof_steps / 1e9, 1),
             "share_of_step_time": round(ms / n_prof_steps / ms_step, 3),
-            "events": f"per-launch HIP event pairs on every {PROF_EVERY}th timed step ({n_prof_steps} of {args.steps})",
+            "events": f"per-launch HIP event pairs on every {PROF_EVERY}th timed step ({n_prof_steps} of {args.steps}: steps 0, {PROF_EVERY}, ...)",
         }
         line["kernel_classes_ms_per_step"] = {k: round(v["ms"], 3) for k, v in prof_all.items() if v["launches"]}
         line["kernel_classes_note"] = "HIP-event time per class from one extra untimed step"

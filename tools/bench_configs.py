@@ -16,7 +16,7 @@ EXTRA = {
     1: ["--config", "1", "--steps", "20", "--warmup", "5", "--no-profile"],
     2: ["--config", "2", "--steps", "10", "--warmup", "3"],
     3: ["--config", "3", "--steps", "10", "--warmup", "3"],
-    4: ["--config", "4", "--steps", "4", "--warmup", "1"],      # (profiled on every 4th timed step: the line carries `roofline`)
+    4: ["--config", "4", "--steps", "4", "--warmup", "1"],      # (its first timed step is profiled: the line carries `roofline`)
     5: ["--config", "5", "--steps", "4", "--warmup", "1"],
 }
 
