@@ -872,6 +872,28 @@ def main():
     # contract times inputs resident in HBM), reported next to it.  "serial": one pinned -> device copy on the launch stream in
     # front of every step; "feeder": the product's longform feeding path (feeder.BatchFeeder: the batch is assembled in a
     # pinned staging buffer and copied on a side stream while the previous step's kernels run).
+    # pipelined leg (configs 2 / 1 ragged or not, one rank, CTC): the same K batches with the ids of batch n collected AFTER batch n + 1 is
+    # launched -- what transcribe_longform / shard.run_sharded do and what config 3's step already is; the D2H copy and the host-side list
+    # building then run under the next batch's kernels.  Reported beside `value` (whose step ends with its own ids on the host), never as it.
+    pipe_leg = None
+    if n_ranks == 1 and cfgno == 2 and not is_rnnt and not args.no_h2d_leg:
+        k_p = max(3, min(args.steps, 10))
+        ragged_host(decode_dev(wav, wlen))
+        barrier_sync()
+        t0 = time.perf_counter()
+        pend = None
+        for _ in range(k_p):
+            nxt = decode_dev(wav, wlen)
+            if pend is not None:
+                ragged_host(pend)
+            pend = nxt
+        ragged_host(pend)
+        barrier_sync()
+        t_pipe = (time.perf_counter() - t0) / k_p
+        pipe_leg = {"ms_per_step": round(t_pipe * 1e3, 3), "value": round(audio_s / t_pipe, 1), "steps": k_p,
+                    "note": "ids of batch n collected after batch n + 1 is launched (the product's launch_batch / collect_batch pipeline); "
+                            "informational -- `value` ends every step with its own ids on the host"}
+
     h2d_leg = None
     if n_ranks == 1 and cfgno == 2 and not args.no_h2d_leg:
         from gigaam_amd.feeder import BatchFeeder
@@ -1071,6 +1093,8 @@ def main():
             r = line["roofline"]
             r["avg_sclk_mhz_under_load"] = power["avg_sclk_mhz"]
             r["frac_at_measured_clock"] = round(r["frac"] * PEAK_SCLK_MHZ / power["avg_sclk_mhz"], 4)
+    if pipe_leg is not None:
+        line["pipelined"] = pipe_leg
     if h2d_leg is not None:
         line["h2d_ms"] = h2d_leg["ms_per_step_feeder"]
         line["h2d"] = h2d_leg

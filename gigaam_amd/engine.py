@@ -260,11 +260,12 @@ class HipEngine:
                 host = whole.cpu()
             whole.record_stream(side)
             b, cap = ids.shape
-            n = host[2 * b * cap:].tolist()
+            arr = host.numpy()      # (zero-copy; numpy row slices convert to lists at half the cost of per-row Tensor.tolist(): 0.33 -> 0.17 ms at 32 x 502)
+            n = arr[2 * b * cap:].tolist()
             flag = HipEngine._flag_of(n.pop())
             if n and min(n) < 0:
                 raise GigaAMHipError("decode left an utterance undecoded (counts = -1)")
-            ids_h, fr_h = host[: b * cap].view(b, cap), host[b * cap: 2 * b * cap].view(b, cap)
+            ids_h, fr_h = arr[: b * cap].reshape(b, cap), arr[b * cap: 2 * b * cap].reshape(b, cap)
             return [(ids_h[i, :c].tolist(), fr_h[i, :c].tolist()) for i, c in enumerate(n)], flag
         if evt is not None and ids.is_cuda:
             side = HipEngine._collect_stream(ids.device)
@@ -287,7 +288,8 @@ class HipEngine:
             ids_h, fr_h = ids[:, :width].cpu(), frames[:, :width].cpu()
         if n and min(n) < 0:   # cannot happen: gam_rnnt_greedy repairs failed clusters itself (gam_api.hip launch_single)
             raise GigaAMHipError("RNN-T decode left an utterance undecoded (counts = -1)")
-        return [(ids_h[i, :c].tolist(), fr_h[i, :c].tolist()) for i, c in enumerate(n)], flag
+        ids_a, fr_a = ids_h.numpy(), fr_h.numpy()
+        return [(ids_a[i, :c].tolist(), fr_a[i, :c].tolist()) for i, c in enumerate(n)], flag
 
     def feat_frames(self, n_samples: int) -> int:
         return int(self.lib.gam_feat_frames(self._h, n_samples))
