@@ -208,6 +208,8 @@ class HipEngine:
         return evt, st
 
     _aux_streams: Dict[int, Tuple["torch.cuda.Stream", "torch.cuda.Stream", "torch.cuda.Stream"]] = {}
+    import threading as _threading
+    _aux_lock = _threading.Lock()
     import os as _os
     ONE_COPY_BYTES = int(_os.environ.get("GAM_ONE_COPY_BYTES", str(256 * 1024)))   # decodes up to this size reach the host in one copy (collect); 0: A/B switch
 
@@ -223,8 +225,11 @@ class HipEngine:
         st = cls._aux_streams.get(key)
         if st is None:
             import os
-            prio = int(os.environ.get("GAM_AUX_STREAM_PRIORITY", "-1"))     # (0: the A/B switch of profiles/r06_queue_probe.txt)
-            st = cls._aux_streams[key] = tuple(torch.cuda.Stream(device, priority=prio) for _ in range(3))
+            with cls._aux_lock:      # (two threads building their first engine at once must end up with ONE trio)
+                st = cls._aux_streams.get(key)
+                if st is None:
+                    prio = int(os.environ.get("GAM_AUX_STREAM_PRIORITY", "-1"))     # (0: the A/B switch of profiles/r06_queue_probe.txt)
+                    st = cls._aux_streams[key] = tuple(torch.cuda.Stream(device, priority=prio) for _ in range(3))
         return st
 
     @classmethod
